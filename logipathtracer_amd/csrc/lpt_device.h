@@ -1,0 +1,364 @@
+// Device-side scene layout, two-level BVH traversal and surface shading for the
+// path-tracing kernels.  Follows shaders/path_tracing.comp of the reference in
+// behaviour (visit order, arithmetic, random-number order); the data layout is
+// derived at upload time from the interchange buffers for wide, aligned loads.
+#pragma once
+#include "../../include/lpt.h"
+#include "lpt_bsdf.h"
+
+#pragma clang fp contract(off)
+
+namespace lpt {
+
+// shaders/path_tracing.comp:21
+constexpr uint32_t kRussianRouletteBounces = 2;
+
+// ---- traversal references -------------------------------------------------------
+// A reference is what the traversal stack holds (the reference shader's stack holds
+// node indices, path_tracing.comp:141,181).  Inner node: index into the derived
+// node array.  Leaf: bit 31 set, bits 24..30 = primitive count (<=127), bits 0..23 =
+// first primitive (mesh-relative triangle, or object index in the object tree).
+constexpr uint32_t kRefLeafBit = 0x80000000u;
+constexpr uint32_t kRefSentinel = 0xFFFFFFFFu;  // bottom of stack ("-1" in the shader)
+constexpr uint32_t kRefMarker = 0x7FFFFFFFu;    // end of an object's mesh tree
+constexpr uint32_t kMaxLeafCount = 127u;
+constexpr uint32_t kMaxLeafFirst = 0x00FFFFFEu;
+
+__host__ __device__ inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) {
+  return kRefLeafBit | (count << 24) | first;
+}
+
+// Derived inner node, 64 B: the boxes of BOTH children (the interchange node,
+// path_tracing.comp:29-39, stores its own box, so a visit there costs three node
+// fetches; here it costs one).
+struct alignas(16) TNode {
+  float c0min[3], c0max[3];
+  float c1min[3], c1max[3];
+  uint32_t ref0, ref1;
+  uint32_t pad[2];
+};
+static_assert(sizeof(TNode) == 64, "TNode must be 64 bytes");
+
+// Triangle for intersection: corner 0 and the two edges of ray.glsl:64-65.
+struct alignas(16) Tri {
+  float v0[3], pad0;
+  float e1[3], pad1;
+  float e2[3], pad2;
+};
+static_assert(sizeof(Tri) == 48, "Tri must be 48 bytes");
+
+// Per-object record for traversal, 64 B.
+struct alignas(16) ObjTrav {
+  float inv[12];     // worldMatrixInverse rows 0..2: (m0 m4 m8 m12), (m1 ...), (m2 ...)
+  uint32_t rootRef;  // reference of the mesh tree's root (never box-tested, path_tracing.comp:144)
+  uint32_t triBase;  // verticesOffset / 3
+  uint32_t pad[2];
+};
+static_assert(sizeof(ObjTrav) == 64, "ObjTrav must be 64 bytes");
+
+// Per-object record for shading, 128 B.
+struct alignas(16) ObjShade {
+  float inv[12];        // as in ObjTrav
+  float nrm[9];         // mat3(worldMatrix) rows
+  float baseLinear[3];  // SRGBToLinear(baseColorFactor.rgb), path_tracing.comp:263
+  float emission[3];
+  float roughness;      // max(roughnessFactor, 0.001), path_tracing.comp:238
+  float metallic;
+  float transmission;
+  float ior;
+  float pad;
+};
+static_assert(sizeof(ObjShade) == 128, "ObjShade must be 128 bytes");
+
+struct DScene {
+  const TNode* tlas;
+  const TNode* blas;
+  const Tri* tris;
+  const ObjTrav* otrav;
+  const ObjShade* oshade;
+  const lpt_vertex* verts;
+  uint32_t tlasRootRef;
+};
+
+struct Hit {
+  float t;
+  uint32_t obj;
+  uint32_t prim;  // index of the triangle's first vertex (path_tracing.comp:155)
+};
+
+__device__ __forceinline__ f3 xform_point(const float* r, f3 p) {
+  return f3{((r[0] * p.x + r[1] * p.y) + r[2] * p.z) + r[3], ((r[4] * p.x + r[5] * p.y) + r[6] * p.z) + r[7],
+            ((r[8] * p.x + r[9] * p.y) + r[10] * p.z) + r[11]};
+}
+__device__ __forceinline__ f3 xform_dir(const float* r, f3 v) {
+  return f3{(r[0] * v.x + r[1] * v.y) + r[2] * v.z, (r[4] * v.x + r[5] * v.y) + r[6] * v.z,
+            (r[8] * v.x + r[9] * v.y) + r[10] * v.z};
+}
+__device__ __forceinline__ f3 xform_mat3(const float* r, f3 v) {
+  return f3{(r[0] * v.x + r[1] * v.y) + r[2] * v.z, (r[3] * v.x + r[4] * v.y) + r[5] * v.z,
+            (r[6] * v.x + r[7] * v.y) + r[8] * v.z};
+}
+
+// shaders/common/ray.glsl:39-61 with the reciprocal direction hoisted out (it is
+// recomputed there from the same direction on every call).
+__device__ __forceinline__ bool box_test(f3 o, f3 inv, const float* mn, const float* mx, float dist) {
+  float nx = (mn[0] - o.x) * inv.x, ny = (mn[1] - o.y) * inv.y, nz = (mn[2] - o.z) * inv.z;
+  float fx = (mx[0] - o.x) * inv.x, fy = (mx[1] - o.y) * inv.y, fz = (mx[2] - o.z) * inv.z;
+  float t0 = max_num(max_num(min_num(nx, fx), min_num(ny, fy)), min_num(nz, fz));
+  float t1 = min_num(min_num(max_num(nx, fx), max_num(ny, fy)), max_num(nz, fz));
+  if (t0 > t1) return false;
+  if (t0 > 0.0f) return t0 < dist;
+  return t1 > 0.0f;
+}
+
+// shaders/common/ray.glsl:63-82 (Moeller-Trumbore, no culling, no parallel check)
+__device__ __forceinline__ float tri_test(f3 o, f3 d, f3 v0, f3 e1, f3 e2) {
+  f3 pvec = cross3(d, e2);
+  float det = 1.0f / dot3(e1, pvec);
+  f3 tvec = o - v0;
+  float u = dot3(tvec, pvec) * det;
+  if (u < 0.0f || u > 1.0f) return kInfinity;
+  f3 qvec = cross3(tvec, e1);
+  float v = dot3(d, qvec) * det;
+  if (v < 0.0f || u + v > 1.0f) return kInfinity;
+  return dot3(e2, qvec) * det;
+}
+
+// Closest hit along (o,d): sceneIntersect + objectIntersect of
+// shaders/path_tracing.comp:130-209 on one shared stack.  `stk` points at this
+// thread's column of an LDS array laid out [entry][thread]; `stride` is the
+// number of threads per entry row.  The caller guarantees the scene's stack
+// need (computed at upload) fits the array.
+// Visit order is the shader's: children are tested in index order (x then y),
+// pushed in that order and popped last-in-first-out, so y is visited first;
+// a hit replaces the current one only if strictly closer.
+__device__ __forceinline__ Hit intersect_scene(const DScene& sc, f3 wo, f3 wd, uint32_t* stk, int stride) {
+  Hit hit{kInfinity, 0u, 0u};
+  const f3 winv{1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z};
+  f3 co = wo, cd = wd, cinv = winv;
+  const TNode* nodes = sc.tlas;
+  bool inObj = false;
+  uint32_t curObj = 0, triBase = 0;
+  int sp = 0;
+  stk[0] = kRefSentinel;
+  sp = 1;
+  uint32_t cur = sc.tlasRootRef;
+
+  while (cur != kRefSentinel) {
+    if (cur == kRefMarker) {  // finished an object's mesh tree: back to world space
+      inObj = false;
+      co = wo;
+      cd = wd;
+      cinv = winv;
+      nodes = sc.tlas;
+      cur = stk[(--sp) * stride];
+      continue;
+    }
+    if (!(cur & kRefLeafBit)) {
+      const float4* q = reinterpret_cast<const float4*>(nodes + cur);
+      float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+      float c0mn[3] = {q0.x, q0.y, q0.z}, c0mx[3] = {q0.w, q1.x, q1.y};
+      float c1mn[3] = {q1.z, q1.w, q2.x}, c1mx[3] = {q2.y, q2.z, q2.w};
+      bool h0 = box_test(co, cinv, c0mn, c0mx, hit.t);
+      bool h1 = box_test(co, cinv, c1mn, c1mx, hit.t);
+      uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+      if (h1) {
+        if (h0) stk[(sp++) * stride] = r0;
+        cur = r1;
+      } else if (h0) {
+        cur = r0;
+      } else {
+        cur = stk[(--sp) * stride];
+      }
+      continue;
+    }
+    uint32_t first = cur & 0x00FFFFFFu;
+    uint32_t count = (cur >> 24) & 0x7Fu;
+    if (inObj) {
+      for (uint32_t i = first; i < first + count; ++i) {
+        const float4* tq = reinterpret_cast<const float4*>(sc.tris + (triBase + i));
+        float4 a = tq[0], b = tq[1], c = tq[2];
+        float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
+        if (td > kEps && td < hit.t) {
+          hit.t = td;
+          hit.obj = curObj;
+          hit.prim = 3u * (triBase + i);
+        }
+      }
+      cur = stk[(--sp) * stride];
+    } else {
+      if (count == 0u) {
+        cur = stk[(--sp) * stride];
+        continue;
+      }
+      if (count > 1u) stk[(sp++) * stride] = make_leaf_ref(first + 1u, count - 1u);
+      stk[(sp++) * stride] = kRefMarker;
+      const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
+      float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
+      float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+      co = xform_point(rows, wo);
+      cd = xform_dir(rows, wd);
+      cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
+      curObj = first;
+      triBase = as_uint(r3.y);
+      nodes = sc.blas;
+      inObj = true;
+      cur = as_uint(r3.x);
+    }
+  }
+  return hit;
+}
+
+// ---- path state ------------------------------------------------------------------
+
+struct Path {
+  f3 o, d;     // current ray (world space)
+  f3 mask;     // throughput
+  f3 acc;      // radiance gathered so far
+  Rng rng;
+};
+
+// shaders/path_tracing.comp:107-127 for global pixel (px,py) of a resx x resy image
+__device__ __forceinline__ void generate_ray(const lpt_ubo& ubo, int px, int py, float resx, float resy, Path& p) {
+  p.rng.x = ubo.seed[0] * (uint32_t)px;  // path_tracing.comp:341
+  p.rng.y = ubo.seed[1] * (uint32_t)py;
+  float r1 = 2.0f * rand01(p.rng);
+  float r2 = 2.0f * rand01(p.rng);
+  float jx = r1 < 1.0f ? __builtin_sqrtf(r1) - 1.0f : 1.0f - __builtin_sqrtf(2.0f - r1);
+  float jy = r2 < 1.0f ? __builtin_sqrtf(r2) - 1.0f : 1.0f - __builtin_sqrtf(2.0f - r2);
+  jx = jx / (resx * 0.5f);
+  jy = jy / (resy * 0.5f);
+  float uvx = ((2.0f * (float)px) / resx - 1.0f) + jx;
+  float uvy = ((2.0f * (float)py) / resy - 1.0f) + jy;
+  const float* m = ubo.cameraWorldMatrix;
+  float aspect = resx / resy;
+  float th = tan_fixed(ubo.fovY / 2.0f);
+  uvx = uvx * (aspect * th);
+  uvy = uvy * th;
+  f3 c0{m[0], m[1], m[2]}, c1{m[4], m[5], m[6]}, c2{m[8], m[9], m[10]};
+  p.o = f3{m[12], m[13], m[14]};
+  p.d = normalize3((c0 * uvx + c1 * uvy) - c2);
+  p.mask = f3{1.0f, 1.0f, 1.0f};
+  p.acc = f3{0.0f, 0.0f, 0.0f};
+}
+
+// shaders/common/util.glsl:23-41
+__device__ __forceinline__ f3 barycentric(f3 point, f3 v0, f3 v1, f3 v2) {
+  f3 ab = v1 - v0, ac = v2 - v0, ah = point - v0;
+  float ab_ab = dot3(ab, ab), ab_ac = dot3(ab, ac), ac_ac = dot3(ac, ac);
+  float ab_ah = dot3(ab, ah), ac_ah = dot3(ac, ah);
+  float inv_denom = 1.0f / (ab_ab * ac_ac - ab_ac * ab_ac);
+  float v = (ac_ac * ab_ah - ab_ac * ac_ah) * inv_denom;
+  float w = (ab_ab * ac_ah - ab_ac * ab_ah) * inv_denom;
+  float u = (1.0f - v) - w;
+  return f3{u, v, w};
+}
+
+// One iteration of traceRay's loop after the intersection is known
+// (shaders/path_tracing.comp:219-323).  Returns true if the path goes on to
+// bounce+1; otherwise `sample` holds the path's radiance.
+__device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& hit, uint32_t bounce,
+                                          uint32_t maxBounces, int bsdfMode, f3& sample) {
+  if (hit.t == kInfinity) {  // :220-223 — assignment: radiance gathered so far is dropped
+    sample = p.mask * 0.2f;
+    return false;
+  }
+  const float4* sq = reinterpret_cast<const float4*>(sc.oshade + hit.obj);
+  float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3], s4 = sq[4], s5 = sq[5], s6 = sq[6], s7 = sq[7];
+  float inv[12] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+  float nrm[9] = {s3.x, s3.y, s3.z, s3.w, s4.x, s4.y, s4.z, s4.w, s5.x};
+  f3 baseLinear{s5.y, s5.z, s5.w};
+  f3 emission{s6.x, s6.y, s6.z};
+  float roughness = s6.w, metallic = s7.x, transmission = s7.y, ior = s7.z;
+
+  const float4* vq = reinterpret_cast<const float4*>(sc.verts + hit.prim);
+  float4 p0 = vq[0], n0 = vq[1], p1 = vq[3], n1 = vq[4], p2 = vq[6], n2 = vq[7];
+
+  f3 oo = xform_point(inv, p.o);
+  f3 od = xform_dir(inv, p.d);
+  f3 posW = p.o + p.d * hit.t;
+  f3 bary = barycentric(oo + od * hit.t, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z});
+
+  uint32_t interaction = pick_interaction(p.rng, metallic, transmission);  // :266
+  p.acc = p.acc + p.mask * emission;                                       // :269
+
+  f3 nsum = (f3{n0.x, n0.y, n0.z} * bary.x + f3{n1.x, n1.y, n1.z} * bary.y) + f3{n2.x, n2.y, n2.z} * bary.z;
+  f3 normal = normalize3(xform_mat3(nrm, nsum));  // :272 (mat3(worldMatrix), not inverse-transpose)
+  f3 ff = (dot3(normal, p.d) < 0.0f) ? normal : normal * -1.0f;
+  f3 axis = (__builtin_fabsf(ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
+  f3 u = normalize3(cross3(axis, ff));
+  f3 v = cross3(ff, u);
+  f3 nd = -p.d;
+  f3 viewDir{dot3(nd, u), dot3(nd, v), dot3(nd, ff)};
+  f3 lightDir{0.0f, 0.0f, 0.0f};
+
+  if (interaction == kDiff) {
+    p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ ? diffuse_bsdf(p.rng, baseLinear, viewDir, roughness, lightDir)
+                                                  : basic_diffuse(p.rng, baseLinear, lightDir));
+  } else if (interaction == kMetallic) {
+    p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ ? conductor_brdf(p.rng, baseLinear, viewDir, roughness, lightDir)
+                                                  : basic_specular(baseLinear, viewDir, lightDir));
+  } else if (interaction == kTrans) {
+    bool outside = dot3(normal, nd) > 0.0f;  // :304 — the unflipped normal
+    p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ
+                           ? dielectric_bsdf(p.rng, baseLinear, viewDir, roughness, ior, lightDir, outside)
+                           : basic_transmittance(p.rng, baseLinear, viewDir, transmission, ior, outside, lightDir));
+  }
+
+  p.d = (u * lightDir.x + v * lightDir.y) + ff * lightDir.z;  // :312
+  p.o = posW;                                                  // no origin offset; EPS guards self-hits
+
+  float q = max_num(max_num(p.mask.x, p.mask.y), p.mask.z);  // :317-323
+  if (q < 0.5f && bounce > kRussianRouletteBounces) {
+    if (rand01(p.rng) > q) {
+      sample = p.acc;
+      return false;
+    }
+    p.mask = p.mask * (1.0f / q);
+  }
+  if (bounce + 1u >= maxBounces) {
+    sample = p.acc;
+    return false;
+  }
+  return true;
+}
+
+// ---- pixel ownership ---------------------------------------------------------------
+// A context owns the tiles g with g % nRanks == rank.  Owned pixels live in a
+// compact buffer: slot = localTile * tileW*tileH + (8x8 block, row-major) * 64 +
+// (y%8)*8 + (x%8), so 64 consecutive slots are one 8x8 pixel block.
+struct Partition {
+  int W, H;
+  int tileW, tileH;
+  int tilesX, tilesY;
+  int rank, nRanks;
+  int nLocalTiles;   // ceil(tilesX*tilesY / nRanks), equal on every rank
+  uint32_t nSlots;   // nLocalTiles * tileW * tileH
+};
+
+__device__ __forceinline__ bool slot_to_pixel(const Partition& P, uint32_t slot, int& x, int& y) {
+  uint32_t perTile = (uint32_t)(P.tileW * P.tileH);
+  uint32_t k = slot / perTile, r = slot - k * perTile;
+  uint32_t g = k * (uint32_t)P.nRanks + (uint32_t)P.rank;
+  if (g >= (uint32_t)(P.tilesX * P.tilesY)) return false;
+  int tx = (int)(g % (uint32_t)P.tilesX), ty = (int)(g / (uint32_t)P.tilesX);
+  uint32_t blk = r >> 6, in = r & 63u;
+  uint32_t bpr = (uint32_t)(P.tileW >> 3);
+  int bx = (int)(blk % bpr), by = (int)(blk / bpr);
+  x = tx * P.tileW + bx * 8 + (int)(in & 7u);
+  y = ty * P.tileH + by * 8 + (int)(in >> 3);
+  return x < P.W && y < P.H;
+}
+
+// Inverse map: owner rank and slot of pixel (x,y).
+__device__ __forceinline__ void pixel_to_slot(const Partition& P, int x, int y, int& owner, uint32_t& slot) {
+  int tx = x / P.tileW, ty = y / P.tileH;
+  uint32_t g = (uint32_t)(ty * P.tilesX + tx);
+  owner = (int)(g % (uint32_t)P.nRanks);
+  uint32_t k = g / (uint32_t)P.nRanks;
+  int lx = x - tx * P.tileW, ly = y - ty * P.tileH;
+  uint32_t blk = (uint32_t)((ly >> 3) * (P.tileW >> 3) + (lx >> 3));
+  slot = k * (uint32_t)(P.tileW * P.tileH) + blk * 64u + (uint32_t)((ly & 7) * 8 + (lx & 7));
+}
+
+}  // namespace lpt

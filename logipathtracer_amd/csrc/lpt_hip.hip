@@ -1,0 +1,1014 @@
+// HIP kernels and C-ABI of the MI355X device layer (see include/lpt.h).
+//
+// Two kernel organisations render identical pixels:
+//  * wavefront: Structure-of-Arrays path queues in HBM; per bounce one traversal
+//    kernel (k_extend, node stack in LDS) and one shading kernel (k_shade) that
+//    compacts surviving paths into the next queue with a wave ballot;
+//  * megakernel: one thread per pixel runs the whole path (the organisation of
+//    shaders/path_tracing.comp::main).
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+//          -fhip-fp32-correctly-rounded-divide-sqrt (no fast-math).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lpt_device.h"
+#include "lpt_internal.h"
+
+#pragma clang fp contract(off)
+
+using namespace lpt;
+
+static_assert(sizeof(lpt_object) == 208, "GPUObjectData layout");
+static_assert(sizeof(lpt_vertex) == 48, "GPUVertex layout");
+static_assert(sizeof(lpt_bvh_node) == 48, "GPUBVHNode layout");
+static_assert(sizeof(lpt_ubo) == 92, "PathTracerUBO layout");
+static_assert(offsetof(lpt_object, bvhOffset) == 192 && offsetof(lpt_object, ior) == 168, "GPUObjectData offsets");
+static_assert(offsetof(lpt_bvh_node, isLeaf) == 28 && offsetof(lpt_bvh_node, indices) == 32, "GPUBVHNode offsets");
+static_assert(offsetof(lpt_ubo, seed) == 80 && offsetof(lpt_ubo, reset) == 88, "UBO offsets");
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// Path queue, Structure of Arrays; slot i of each array belongs to one path.
+struct Queue {
+  float4* o;  // origin.xyz, path id (bits)
+  float4* d;  // direction.xyz, unused
+  float4* m;  // throughput.rgb, rng.x (bits)
+  float4* a;  // gathered radiance.rgb, rng.y (bits)
+};
+
+// Wave-level append: every lane with `active` gets a distinct slot of a queue whose
+// fill count lives in *counter; one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(bool active, uint32_t* counter) {
+  unsigned long long ballot = __ballot(active);
+  uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+  uint32_t total = (uint32_t)__popcll(ballot);
+  uint32_t base = 0;
+  if (active && below == 0u) base = atomicAdd(counter, total);
+  int leader = ballot ? (__ffsll((long long)ballot) - 1) : 0;
+  base = (uint32_t)__shfl((int)base, leader);
+  return base + below;
+}
+
+__device__ __forceinline__ void store_path(const Queue& q, uint32_t slot, const Path& p, uint32_t pid) {
+  q.o[slot] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pid));
+  q.d[slot] = make_float4(p.d.x, p.d.y, p.d.z, 0.0f);
+  q.m[slot] = make_float4(p.mask.x, p.mask.y, p.mask.z, as_float(p.rng.x));
+  q.a[slot] = make_float4(p.acc.x, p.acc.y, p.acc.z, as_float(p.rng.y));
+}
+
+// ---- wavefront kernels ---------------------------------------------------------------
+
+// Camera rays for `nFrames` frames of the owned pixels (path id = frame*nSlots + slot).
+__global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
+                                                     Queue q, uint32_t* count) {
+  const uint32_t total = nFrames * P.nSlots;
+  for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
+    uint32_t pid = base + threadIdx.x;
+    bool active = false;
+    Path p;
+    if (pid < total) {
+      uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
+      int x, y;
+      if (slot_to_pixel(P, slot, x, y)) {
+        generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
+        active = true;
+      }
+    }
+    uint32_t dst = wave_append(active, count);
+    if (active) store_path(q, dst, p, pid);
+  }
+}
+
+// Closest hit for every queued ray; the traversal stack lives in LDS, one column per thread.
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
+                                                   const float4* __restrict__ qd, const uint32_t* __restrict__ count,
+                                                   float4* __restrict__ hits) {
+  __shared__ uint32_t stack[S * kBlock];
+  const uint32_t n = *count;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 o = qo[i], d = qd[i];
+    Hit h = intersect_scene(sc, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, &stack[threadIdx.x], kBlock);
+    hits[i] = make_float4(h.t, as_float(h.obj), as_float(h.prim), 0.0f);
+  }
+}
+
+// Shades every queued hit, samples the next direction, applies Russian roulette; paths
+// that go on are appended to `out`, finished paths write their radiance to `samples[pid]`.
+__global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const float4* __restrict__ hits,
+                                                  const uint32_t* __restrict__ countIn, Queue out, uint32_t* countOut,
+                                                  float4* __restrict__ samples, uint32_t bounce, uint32_t maxBounces,
+                                                  int bsdfMode) {
+  const uint32_t n = *countIn;
+  for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    uint32_t i = base + threadIdx.x;
+    bool alive = false;
+    Path p;
+    uint32_t pid = 0;
+    if (i < n) {
+      float4 o = in.o[i], d = in.d[i], m = in.m[i], a = in.a[i], h = hits[i];
+      p.o = f3{o.x, o.y, o.z};
+      p.d = f3{d.x, d.y, d.z};
+      p.mask = f3{m.x, m.y, m.z};
+      p.acc = f3{a.x, a.y, a.z};
+      p.rng = Rng{as_uint(m.w), as_uint(a.w)};
+      pid = as_uint(o.w);
+      Hit hit{h.x, as_uint(h.y), as_uint(h.z)};
+      f3 s;
+      alive = shade_hit(sc, p, hit, bounce, maxBounces, bsdfMode, s);
+      if (!alive) samples[pid] = make_float4(s.x, s.y, s.z, 0.0f);
+    }
+    uint32_t dst = wave_append(alive, countOut);
+    if (alive) store_path(out, dst, p, pid);
+  }
+}
+
+// Adds the finished frames to the accumulation image in frame order
+// (shaders/path_tracing.comp:347-351: reset stores (rgb,1), otherwise adds (rgb,1)).
+__global__ __launch_bounds__(kBlock) void k_accumulate(Partition P, const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
+                                                       const float4* __restrict__ samples, float4* __restrict__ accum) {
+  for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < P.nSlots; slot += gridDim.x * kBlock) {
+    int x, y;
+    if (!slot_to_pixel(P, slot, x, y)) continue;
+    float4 a = accum[slot];
+    for (uint32_t f = 0; f < nFrames; ++f) {
+      float4 s = samples[(size_t)f * P.nSlots + slot];
+      if (ubos[f].reset) {
+        a = make_float4(s.x, s.y, s.z, 1.0f);
+      } else {
+        a = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + 1.0f);
+      }
+    }
+    accum[slot] = a;
+  }
+}
+
+// totals[0] += paths started, totals[1] += ray segments traced (queue fills per bounce).
+__global__ void k_tally(const uint32_t* __restrict__ counts, uint32_t nBounces, unsigned long long* totals) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long seg = 0;
+    for (uint32_t b = 0; b < nBounces; ++b) seg += counts[b];
+    totals[0] += counts[0];
+    totals[1] += seg;
+  }
+}
+
+// ---- megakernel --------------------------------------------------------------------
+
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_megakernel(DScene sc, Partition P, lpt_ubo ubo, uint32_t maxBounces,
+                                                       int bsdfMode, float4* __restrict__ accum,
+                                                       unsigned long long* totals) {
+  __shared__ uint32_t stack[S * kBlock];
+  uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t segments = 0, started = 0;
+  int x, y;
+  if (slot < P.nSlots && slot_to_pixel(P, slot, x, y)) {
+    started = 1;
+    Path p;
+    generate_ray(ubo, x, y, (float)P.W, (float)P.H, p);
+    f3 s{0.0f, 0.0f, 0.0f};
+    for (uint32_t bounce = 0; bounce < maxBounces; ++bounce) {
+      ++segments;
+      Hit h = intersect_scene(sc, p.o, p.d, &stack[threadIdx.x], kBlock);
+      if (!shade_hit(sc, p, h, bounce, maxBounces, bsdfMode, s)) break;
+    }
+    if (ubo.reset) {
+      accum[slot] = make_float4(s.x, s.y, s.z, 1.0f);
+    } else {
+      float4 a = accum[slot];
+      accum[slot] = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + 1.0f);
+    }
+  }
+  // per-wave reduction of the counters, one atomic pair per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    segments += (uint32_t)__shfl_down((int)segments, off);
+    started += (uint32_t)__shfl_down((int)started, off);
+  }
+  if ((threadIdx.x & 63) == 0 && started) {
+    atomicAdd(&totals[0], (unsigned long long)started);
+    atomicAdd(&totals[1], (unsigned long long)segments);
+  }
+}
+
+// ---- image kernels -------------------------------------------------------------------
+
+// Compact owned-pixel buffer -> scan-line image (pixels of other ranks become 0).
+__global__ void k_unpermute(Partition P, const float4* __restrict__ accum, float4* __restrict__ image) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.W || y >= P.H) return;
+  int owner;
+  uint32_t slot;
+  pixel_to_slot(P, x, y, owner, slot);
+  image[(size_t)y * P.W + x] = owner == P.rank ? accum[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Concatenated compact buffers of all ranks -> scan-line image.
+__global__ void k_assemble(Partition P, const float4* __restrict__ gathered, float4* __restrict__ image) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.W || y >= P.H) return;
+  int owner;
+  uint32_t slot;
+  pixel_to_slot(P, x, y, owner, slot);
+  image[(size_t)y * P.W + x] = gathered[(size_t)owner * P.nSlots + slot];
+}
+
+// shaders/tex_to_quad.frag:24-33: display row y shows accumulation row H-1-y.
+__global__ void k_resolve(Partition P, const float4* __restrict__ accum, float invSampleCount,
+                          float4* __restrict__ image) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.W || y >= P.H) return;
+  int owner;
+  uint32_t slot;
+  pixel_to_slot(P, x, P.H - 1 - y, owner, slot);
+  float4 out = make_float4(0.f, 0.f, 0.f, 1.f);
+  if (owner == P.rank) {
+    float4 a = accum[slot];
+    const float exposure = 1.5f, invGamma = 1.0f / 2.2f;
+    out.x = pow_fixed(1.0f - exp_fixed(-(a.x * invSampleCount) * exposure), invGamma);
+    out.y = pow_fixed(1.0f - exp_fixed(-(a.y * invSampleCount) * exposure), invGamma);
+    out.z = pow_fixed(1.0f - exp_fixed(-(a.z * invSampleCount) * exposure), invGamma);
+  }
+  image[(size_t)y * P.W + x] = out;
+}
+
+// baseLinear = SRGBToLinear(baseColorFactor.rgb) with the device's own pow, so host code
+// never has to reproduce it.
+__global__ void k_finish_objects(ObjShade* os, const float* __restrict__ baseColor, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  os[i].baseLinear[0] = srgb_to_linear(baseColor[4 * i + 0]);
+  os[i].baseLinear[1] = srgb_to_linear(baseColor[4 * i + 1]);
+  os[i].baseLinear[2] = srgb_to_linear(baseColor[4 * i + 2]);
+}
+
+// ---- test hooks ----------------------------------------------------------------------
+
+__global__ void k_debug_math(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                             uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f, s, c;
+  switch (op) {
+    case 0: sincos_fixed(x, s, c); r = s; break;
+    case 1: sincos_fixed(x, s, c); r = c; break;
+    case 2: r = tan_fixed(x); break;
+    case 3: r = log_fixed(x); break;
+    case 4: r = exp_fixed(x); break;
+    case 5: r = pow_fixed(x, y); break;
+    case 6: r = x / y; break;
+    case 7: r = __builtin_sqrtf(x); break;
+    case 8: r = srgb_to_linear(x); break;
+    default: break;
+  }
+  out[i] = r;
+}
+
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_debug_intersect(DScene sc, const float* __restrict__ o,
+                                                            const float* __restrict__ d, uint32_t n,
+                                                            float* __restrict__ t, uint32_t* __restrict__ obj,
+                                                            uint32_t* __restrict__ prim) {
+  __shared__ uint32_t stack[S * kBlock];
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Hit h = intersect_scene(sc, f3{o[3 * i], o[3 * i + 1], o[3 * i + 2]}, f3{d[3 * i], d[3 * i + 1], d[3 * i + 2]},
+                          &stack[threadIdx.x], kBlock);
+  t[i] = h.t;
+  obj[i] = h.obj;
+  prim[i] = h.prim;
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------------------
+
+struct lpt_ctx {
+  int device = 0;
+  hipStream_t ownStream = nullptr;
+  hipStream_t stream = nullptr;
+  int numCUs = 256;
+  std::string err;
+
+  // scene (device)
+  TNode* dTlas = nullptr;
+  TNode* dBlas = nullptr;
+  Tri* dTris = nullptr;
+  ObjTrav* dObjTrav = nullptr;
+  ObjShade* dObjShade = nullptr;
+  lpt_vertex* dVerts = nullptr;
+  uint32_t tlasRootRef = kRefSentinel;
+  int stackNeed = 0;
+  bool sceneLoaded = false;
+
+  // image
+  Partition part{};
+  bool sized = false;
+  float4* dAccum = nullptr;
+  float4* dImage = nullptr;  // scan-line staging for read-back / resolve
+
+  // options
+  int maxBounces = 10;  // MAX_TRACE_DEPTH, shaders/path_tracing.comp:20
+  int bsdfMode = LPT_BSDF_HEITZ;
+  int pipeline = LPT_PIPELINE_WAVEFRONT;
+  int framesInFlight = 0;
+
+  // wavefront pool
+  size_t poolPaths = 0;
+  int poolBounces = 0;
+  float4* dPool = nullptr;  // 2 queues x 4 arrays + hits + samples
+  Queue queues[2]{};
+  float4* dHits = nullptr;
+  float4* dSamples = nullptr;
+  uint32_t* dCounts = nullptr;
+  lpt_ubo* dUbos = nullptr;
+  lpt_ubo* hUbos = nullptr;  // pinned staging
+  int ubosCap = 0;
+  unsigned long long* dTotals = nullptr;  // [0] paths, [1] segments
+
+  // timing of the last lpt_render_frames call
+  hipEvent_t evStart = nullptr, evStop = nullptr;
+  std::vector<hipEvent_t> evPool;
+  size_t evUsed = 0;
+  uint64_t lastFrames = 0;
+  bool haveTiming = false;
+};
+
+namespace {
+
+int fail(lpt_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define LPT_HIP(ctx, call)                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(ctx, LPT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+template <typename T>
+void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+void free_scene(lpt_ctx* c) {
+  dfree(c->dTlas);
+  dfree(c->dBlas);
+  dfree(c->dTris);
+  dfree(c->dObjTrav);
+  dfree(c->dObjShade);
+  dfree(c->dVerts);
+  c->sceneLoaded = false;
+}
+
+void free_pool(lpt_ctx* c) {
+  dfree(c->dPool);
+  dfree(c->dCounts);
+  c->poolPaths = 0;
+  c->poolBounces = 0;
+}
+
+DScene device_scene(const lpt_ctx* c) {
+  return DScene{c->dTlas, c->dBlas, c->dTris, c->dObjTrav, c->dObjShade, c->dVerts, c->tlasRootRef};
+}
+
+// Builds derived inner nodes for the tree rooted at `root` (indices in `nodes` are
+// offset by `base`) and returns the number of stack entries a traversal of it can hold
+// at once, excluding what leaves of the object tree add.  leafNeed(first,count) gives
+// the extra need of a leaf.  Iterative post-order; rejects cycles and bad indices.
+template <typename LeafNeed>
+int derive_tree(const lpt_bvh_node* nodes, uint32_t nNodes, uint32_t base, std::vector<TNode>& out,
+                std::vector<int>& need, uint32_t* rootRef, LeafNeed leafNeed, std::string& err) {
+  if (base >= nNodes) {
+    err = "BVH root index out of range";
+    return LPT_ERR_INVALID;
+  }
+  auto leaf_ref = [&](const lpt_bvh_node& n, uint32_t* ref) -> int {
+    uint32_t first = n.indices[0], last = n.indices[1];
+    uint32_t count = last > first ? last - first : 0u;
+    if (count > kMaxLeafCount || first > kMaxLeafFirst) {
+      err = "BVH leaf range cannot be encoded (more than 127 primitives or first >= 2^24-1)";
+      return LPT_ERR_UNSUPPORTED;
+    }
+    *ref = make_leaf_ref(first, count);
+    return 0;
+  };
+  const lpt_bvh_node& r = nodes[base];
+  if (r.isLeaf) {
+    int rc = leaf_ref(r, rootRef);
+    if (rc) return rc;
+    return leafNeed(r.indices[0], r.indices[1] > r.indices[0] ? r.indices[1] - r.indices[0] : 0u);
+  }
+  *rootRef = base;
+  // need[] doubles as the visit state: -2 unvisited, -1 on stack, >=0 done
+  std::vector<uint32_t> st;
+  st.push_back(base);
+  while (!st.empty()) {
+    uint32_t i = st.back();
+    const lpt_bvh_node& n = nodes[i];
+    uint32_t c[2] = {base + n.indices[0], base + n.indices[1]};
+    if (c[0] >= nNodes || c[1] >= nNodes) {
+      err = "BVH child index out of range";
+      return LPT_ERR_INVALID;
+    }
+    if (need[i] == -2) {
+      need[i] = -1;
+      bool pushed = false;
+      for (int k = 0; k < 2; ++k) {
+        if (!nodes[c[k]].isLeaf) {
+          if (need[c[k]] == -1) {
+            err = "BVH contains a cycle";
+            return LPT_ERR_INVALID;
+          }
+          if (need[c[k]] == -2) {
+            st.push_back(c[k]);
+            pushed = true;
+          }
+        }
+      }
+      if (pushed) continue;
+    }
+    // children done: emit the derived node
+    TNode t{};
+    int cn[2];
+    uint32_t refs[2];
+    for (int k = 0; k < 2; ++k) {
+      const lpt_bvh_node& ch = nodes[c[k]];
+      if (ch.isLeaf) {
+        int rc = leaf_ref(ch, &refs[k]);
+        if (rc) return rc;
+        cn[k] = leafNeed(ch.indices[0], ch.indices[1] > ch.indices[0] ? ch.indices[1] - ch.indices[0] : 0u);
+        if (cn[k] < 0) return cn[k];
+      } else {
+        refs[k] = c[k];
+        cn[k] = need[c[k]];
+      }
+    }
+    std::memcpy(t.c0min, nodes[c[0]].minCorner, 12);
+    std::memcpy(t.c0max, nodes[c[0]].maxCorner, 12);
+    std::memcpy(t.c1min, nodes[c[1]].minCorner, 12);
+    std::memcpy(t.c1max, nodes[c[1]].maxCorner, 12);
+    t.ref0 = refs[0];
+    t.ref1 = refs[1];
+    out[i] = t;
+    // child 1 is walked first while child 0 may wait on the stack
+    need[i] = std::max(1 + cn[1], cn[0]);
+    st.pop_back();
+  }
+  return need[base];
+}
+
+int ensure_events(lpt_ctx* c, size_t n) {
+  while (c->evPool.size() < n) {
+    hipEvent_t e;
+    LPT_HIP(c, hipEventCreate(&e));
+    c->evPool.push_back(e);
+  }
+  return 0;
+}
+
+int auto_frames_in_flight(const lpt_ctx* c) {
+  if (c->framesInFlight > 0) return c->framesInFlight;
+  const double target = 8.0 * 1024 * 1024;  // paths in flight
+  int f = (int)(target / std::max<uint32_t>(c->part.nSlots, 1u));
+  return std::min(64, std::max(1, f));
+}
+
+int ensure_pool(lpt_ctx* c, int frames) {
+  size_t paths = (size_t)frames * c->part.nSlots;
+  if (paths > c->poolPaths) {
+    dfree(c->dPool);
+    // 2 queues x 4 arrays + hits + samples = 10 float4 arrays
+    LPT_HIP(c, hipMalloc(&c->dPool, paths * 10 * sizeof(float4)));
+    float4* p = c->dPool;
+    for (int q = 0; q < 2; ++q) {
+      c->queues[q].o = p; p += paths;
+      c->queues[q].d = p; p += paths;
+      c->queues[q].m = p; p += paths;
+      c->queues[q].a = p; p += paths;
+    }
+    c->dHits = p; p += paths;
+    c->dSamples = p;
+    LPT_HIP(c, hipMemsetAsync(c->dSamples, 0, paths * sizeof(float4), c->stream));
+    c->poolPaths = paths;
+  }
+  if (c->maxBounces + 1 > c->poolBounces) {
+    dfree(c->dCounts);
+    LPT_HIP(c, hipMalloc(&c->dCounts, (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
+    c->poolBounces = c->maxBounces + 1;
+  }
+  if (frames > c->ubosCap) {
+    dfree(c->dUbos);
+    if (c->hUbos) (void)hipHostFree(c->hUbos);
+    c->hUbos = nullptr;
+    LPT_HIP(c, hipMalloc(&c->dUbos, (size_t)frames * sizeof(lpt_ubo)));
+    LPT_HIP(c, hipHostMalloc(&c->hUbos, (size_t)frames * sizeof(lpt_ubo)));
+    c->ubosCap = frames;
+  }
+  return 0;
+}
+
+int grid_for(const lpt_ctx* c, size_t items, int blocksPerCU) {
+  size_t need = (items + kBlock - 1) / kBlock;
+  size_t cap = (size_t)c->numCUs * blocksPerCU;
+  return (int)std::max<size_t>(1, std::min(need, cap));
+}
+
+template <int S>
+int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, size_t maxItems) {
+  // LDS bounds residency: S*1 KiB per block of 256 threads, 160 KiB per CU
+  int perCU = std::max(1, std::min(8, 160 / S));
+  hipLaunchKernelGGL(k_extend<S>, dim3(grid_for(c, maxItems, perCU)), dim3(kBlock), 0, c->stream, device_scene(c), q.o,
+                     q.d, count, c->dHits);
+  return 0;
+}
+
+int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, size_t maxItems) {
+  if (c->stackNeed <= 16) return launch_extend<16>(c, q, count, maxItems);
+  if (c->stackNeed <= 32) return launch_extend<32>(c, q, count, maxItems);
+  return launch_extend<64>(c, q, count, maxItems);
+}
+
+int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
+  int rc = ensure_pool(c, frames);
+  if (rc) return rc;
+  const size_t paths = (size_t)frames * c->part.nSlots;
+  const uint32_t nB = (uint32_t)c->maxBounces;
+  std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
+  LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (size_t)(nB + 1) * sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
+                     (uint32_t)frames, c->queues[0], c->dCounts);
+  rc = ensure_events(c, c->evUsed + 2 * (size_t)nB);
+  if (rc) return rc;
+  for (uint32_t b = 0; b < nB; ++b) {
+    const Queue& in = c->queues[b & 1];
+    const Queue& out = c->queues[(b + 1) & 1];
+    LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
+    dispatch_extend(c, in, c->dCounts + b, paths);
+    LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
+                       c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
+  }
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
+                     (uint32_t)frames, c->dSamples, c->dAccum);
+  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, nB, c->dTotals);
+  LPT_HIP(c, hipGetLastError());
+  return 0;
+}
+
+template <int S>
+void launch_mega(lpt_ctx* c, const lpt_ubo& ubo) {
+  int grid = (int)((c->part.nSlots + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_megakernel<S>, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), c->part, ubo,
+                     (uint32_t)c->maxBounces, c->bsdfMode, c->dAccum, c->dTotals);
+}
+
+int render_frame_mega(lpt_ctx* c, const lpt_ubo& ubo) {
+  if (c->stackNeed <= 16) launch_mega<16>(c, ubo);
+  else if (c->stackNeed <= 32) launch_mega<32>(c, ubo);
+  else launch_mega<64>(c, ubo);
+  LPT_HIP(c, hipGetLastError());
+  return 0;
+}
+
+int set_partition(lpt_ctx* c, int W, int H, int tileW, int tileH, int rank, int nRanks) {
+  Partition P{};
+  P.W = W;
+  P.H = H;
+  P.tileW = tileW;
+  P.tileH = tileH;
+  P.tilesX = (W + tileW - 1) / tileW;
+  P.tilesY = (H + tileH - 1) / tileH;
+  P.rank = rank;
+  P.nRanks = nRanks;
+  P.nLocalTiles = (P.tilesX * P.tilesY + nRanks - 1) / nRanks;
+  size_t slots = (size_t)P.nLocalTiles * tileW * tileH;
+  if (slots >= (1ull << 31)) return fail(c, LPT_ERR_INVALID, "image too large for one context");
+  P.nSlots = (uint32_t)slots;
+  dfree(c->dAccum);
+  dfree(c->dImage);
+  LPT_HIP(c, hipSetDevice(c->device));
+  LPT_HIP(c, hipMalloc(&c->dAccum, slots * sizeof(float4)));
+  LPT_HIP(c, hipMalloc(&c->dImage, (size_t)W * H * sizeof(float4)));
+  LPT_HIP(c, hipMemsetAsync(c->dAccum, 0, slots * sizeof(float4), c->stream));
+  c->part = P;
+  c->sized = true;
+  free_pool(c);
+  return 0;
+}
+
+int ready(lpt_ctx* c) {
+  if (!c) return LPT_ERR_INVALID;
+  if (!c->sceneLoaded) return fail(c, LPT_ERR_INVALID, "no scene uploaded");
+  if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
+  return 0;
+}
+
+}  // namespace
+
+int lpt_internal_device(const lpt_ctx* ctx) { return ctx->device; }
+hipStream_t lpt_internal_stream(const lpt_ctx* ctx) { return ctx->stream; }
+int lpt_internal_fail(lpt_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg); }
+
+// ---------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------
+
+extern "C" {
+
+int lpt_create(int device, lpt_ctx** out) {
+  if (!out) return LPT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return LPT_ERR_HIP;
+  }
+  if (device < 0 || device >= n) {
+    g_create_error = "device index out of range";
+    return LPT_ERR_INVALID;
+  }
+  lpt_ctx* c = new (std::nothrow) lpt_ctx();
+  if (!c) return LPT_ERR_NOMEM;
+  c->device = device;
+  auto bail = [&](const char* what, hipError_t err) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+    lpt_destroy(c);
+    return LPT_ERR_HIP;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+  c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess)
+    return bail("hipStreamCreate", e);
+  c->stream = c->ownStream;
+  if ((e = hipEventCreate(&c->evStart)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&c->evStop)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc(&c->dTotals, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->dTotals, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  *out = c;
+  return LPT_OK;
+}
+
+void lpt_destroy(lpt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_scene(c);
+  free_pool(c);
+  dfree(c->dAccum);
+  dfree(c->dImage);
+  dfree(c->dUbos);
+  dfree(c->dTotals);
+  if (c->hUbos) (void)hipHostFree(c->hUbos);
+  for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
+  if (c->evStart) (void)hipEventDestroy(c->evStart);
+  if (c->evStop) (void)hipEventDestroy(c->evStop);
+  if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+  delete c;
+}
+
+const char* lpt_last_error(const lpt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int lpt_set_stream(lpt_ctx* c, void* hip_stream) {
+  if (!c) return LPT_ERR_INVALID;
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
+  return LPT_OK;
+}
+
+int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const lpt_bvh_node* objBvh,
+                     uint32_t nObjBvh, const lpt_vertex* verts, uint32_t nVerts, const lpt_bvh_node* meshBvh,
+                     uint32_t nMeshBvh) {
+  if (!c) return LPT_ERR_INVALID;
+  if (!objects || !objBvh || !verts || !meshBvh || nObj == 0 || nObjBvh == 0 || nMeshBvh == 0)
+    return fail(c, LPT_ERR_INVALID, "empty scene buffer");
+  if (nVerts % 3u != 0u) return fail(c, LPT_ERR_INVALID, "vertex count is not a multiple of 3");
+  for (uint32_t i = 0; i < nObj; ++i) {
+    const lpt_object& o = objects[i];
+    if ((o.colorTexture & o.emissionTexture & o.metallicRoughnessTexture & o.transmissionTexture & o.normalTexture) !=
+        0xFFFFFFFFu)
+      return fail(c, LPT_ERR_UNSUPPORTED, "textured materials are not supported");
+    if (o.verticesOffset % 3u != 0u || o.verticesOffset > nVerts)
+      return fail(c, LPT_ERR_INVALID, "object verticesOffset is not a triangle boundary inside the vertex buffer");
+    if (o.bvhOffset >= nMeshBvh) return fail(c, LPT_ERR_INVALID, "object bvhOffset out of range");
+  }
+  LPT_HIP(c, hipSetDevice(c->device));
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+
+  std::string err;
+  // mesh trees, one per object
+  std::vector<TNode> blas(nMeshBvh);
+  std::vector<int> needB(nMeshBvh, -2);
+  std::vector<ObjTrav> otrav(nObj);
+  std::vector<ObjShade> oshade(nObj);
+  std::vector<float> baseColor(4 * (size_t)nObj);
+  std::vector<int> objNeed(nObj, 0);
+  const uint32_t nTris = nVerts / 3u;
+  for (uint32_t i = 0; i < nObj; ++i) {
+    const lpt_object& o = objects[i];
+    uint32_t triBase = o.verticesOffset / 3u;
+    uint32_t rootRef = 0;
+    auto triLeaf = [&](uint32_t first, uint32_t count) -> int {
+      if ((size_t)triBase + first + count > nTris) {
+        err = "mesh BVH leaf references triangles outside the vertex buffer";
+        return LPT_ERR_INVALID;
+      }
+      return 0;
+    };
+    int need = derive_tree(meshBvh, nMeshBvh, o.bvhOffset, blas, needB, &rootRef, triLeaf, err);
+    if (need < 0) return fail(c, need, err);
+    objNeed[i] = need;
+    ObjTrav& t = otrav[i];
+    ObjShade& s = oshade[i];
+    const float* mi = o.worldMatrixInverse;
+    const float* mw = o.worldMatrix;
+    for (int r = 0; r < 3; ++r) {
+      for (int k = 0; k < 4; ++k) t.inv[4 * r + k] = s.inv[4 * r + k] = mi[4 * k + r];
+      for (int k = 0; k < 3; ++k) s.nrm[3 * r + k] = mw[4 * k + r];
+    }
+    t.rootRef = rootRef;
+    t.triBase = triBase;
+    t.pad[0] = t.pad[1] = 0;
+    for (int k = 0; k < 3; ++k) {
+      s.baseLinear[k] = 0.0f;
+      s.emission[k] = o.emissionFactor[k];
+    }
+    float rf = o.roughnessFactor;
+    s.roughness = (rf != rf) ? 0.001f : (rf < 0.001f ? 0.001f : rf);  // max(roughness, 0.001)
+    s.metallic = o.metallicFactor;
+    s.transmission = o.transmissionFactor;
+    s.ior = o.ior;
+    s.pad = 0.0f;
+    std::memcpy(&baseColor[4 * (size_t)i], o.baseColorFactor, 16);
+  }
+  // object tree
+  std::vector<TNode> tlas(nObjBvh);
+  std::vector<int> needT(nObjBvh, -2);
+  uint32_t tlasRoot = 0;
+  auto objLeaf = [&](uint32_t first, uint32_t count) -> int {
+    if ((size_t)first + count > nObj) {
+      err = "object BVH leaf references objects outside the object buffer";
+      return LPT_ERR_INVALID;
+    }
+    int worst = 0;
+    for (uint32_t k = first; k < first + count; ++k) worst = std::max(worst, objNeed[k]);
+    return (count > 1u ? 2 : 1) + worst;  // remaining-range entry + end-of-object marker
+  };
+  int needScene = derive_tree(objBvh, nObjBvh, 0, tlas, needT, &tlasRoot, objLeaf, err);
+  if (needScene < 0) return fail(c, needScene, err);
+  int stackNeed = needScene + 1;  // bottom-of-stack sentinel
+  if (stackNeed > 64) return fail(c, LPT_ERR_STACK, "BVH needs a traversal stack deeper than 64 entries");
+
+  std::vector<Tri> tris(nTris);
+  for (uint32_t t = 0; t < nTris; ++t) {
+    const lpt_vertex* v = verts + 3 * (size_t)t;
+    Tri& tr = tris[t];
+    for (int k = 0; k < 3; ++k) {
+      tr.v0[k] = v[0].position[k];
+      tr.e1[k] = v[1].position[k] - v[0].position[k];
+      tr.e2[k] = v[2].position[k] - v[0].position[k];
+    }
+    tr.pad0 = tr.pad1 = tr.pad2 = 0.0f;
+  }
+
+  free_scene(c);
+  float* dBase = nullptr;
+  LPT_HIP(c, hipMalloc(&c->dTlas, tlas.size() * sizeof(TNode)));
+  LPT_HIP(c, hipMalloc(&c->dBlas, blas.size() * sizeof(TNode)));
+  LPT_HIP(c, hipMalloc(&c->dTris, std::max<size_t>(1, tris.size()) * sizeof(Tri)));
+  LPT_HIP(c, hipMalloc(&c->dObjTrav, otrav.size() * sizeof(ObjTrav)));
+  LPT_HIP(c, hipMalloc(&c->dObjShade, oshade.size() * sizeof(ObjShade)));
+  LPT_HIP(c, hipMalloc(&c->dVerts, std::max<size_t>(1, (size_t)nVerts) * sizeof(lpt_vertex)));
+  LPT_HIP(c, hipMalloc(&dBase, baseColor.size() * sizeof(float)));
+  LPT_HIP(c, hipMemcpy(c->dTlas, tlas.data(), tlas.size() * sizeof(TNode), hipMemcpyHostToDevice));
+  LPT_HIP(c, hipMemcpy(c->dBlas, blas.data(), blas.size() * sizeof(TNode), hipMemcpyHostToDevice));
+  if (!tris.empty()) LPT_HIP(c, hipMemcpy(c->dTris, tris.data(), tris.size() * sizeof(Tri), hipMemcpyHostToDevice));
+  LPT_HIP(c, hipMemcpy(c->dObjTrav, otrav.data(), otrav.size() * sizeof(ObjTrav), hipMemcpyHostToDevice));
+  LPT_HIP(c, hipMemcpy(c->dObjShade, oshade.data(), oshade.size() * sizeof(ObjShade), hipMemcpyHostToDevice));
+  if (nVerts) LPT_HIP(c, hipMemcpy(c->dVerts, verts, (size_t)nVerts * sizeof(lpt_vertex), hipMemcpyHostToDevice));
+  LPT_HIP(c, hipMemcpy(dBase, baseColor.data(), baseColor.size() * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_finish_objects, dim3((nObj + 63) / 64), dim3(64), 0, c->stream, c->dObjShade, dBase, nObj);
+  LPT_HIP(c, hipGetLastError());
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dBase);
+  c->tlasRootRef = tlasRoot;
+  c->stackNeed = stackNeed;
+  c->sceneLoaded = true;
+  return LPT_OK;
+}
+
+int lpt_resize(lpt_ctx* c, int width, int height) {
+  if (!c) return LPT_ERR_INVALID;
+  if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return fail(c, LPT_ERR_INVALID, "bad image size");
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  return set_partition(c, width, height, (width + 7) & ~7, (height + 7) & ~7, 0, 1);
+}
+
+int lpt_set_partition(lpt_ctx* c, int tile_w, int tile_h, int rank, int n_ranks) {
+  if (!c) return LPT_ERR_INVALID;
+  if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
+  if (tile_w <= 0 || tile_h <= 0 || (tile_w & 7) || (tile_h & 7)) return fail(c, LPT_ERR_INVALID, "tile size must be a positive multiple of 8");
+  if (n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(c, LPT_ERR_INVALID, "bad rank / n_ranks");
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  return set_partition(c, c->part.W, c->part.H, tile_w, tile_h, rank, n_ranks);
+}
+
+int lpt_set_options(lpt_ctx* c, int max_bounces, int bsdf_mode, int pipeline, int frames_in_flight) {
+  if (!c) return LPT_ERR_INVALID;
+  if (max_bounces < 1 || max_bounces > 4096) return fail(c, LPT_ERR_INVALID, "max_bounces out of range");
+  if (bsdf_mode != LPT_BSDF_HEITZ && bsdf_mode != LPT_BSDF_BASIC) return fail(c, LPT_ERR_INVALID, "bad bsdf_mode");
+  if (pipeline != LPT_PIPELINE_WAVEFRONT && pipeline != LPT_PIPELINE_MEGAKERNEL)
+    return fail(c, LPT_ERR_INVALID, "bad pipeline");
+  if (frames_in_flight < 0 || frames_in_flight > 4096) return fail(c, LPT_ERR_INVALID, "bad frames_in_flight");
+  c->maxBounces = max_bounces;
+  c->bsdfMode = bsdf_mode;
+  c->pipeline = pipeline;
+  c->framesInFlight = frames_in_flight;
+  return LPT_OK;
+}
+
+int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!ubos || n_frames <= 0) return fail(c, LPT_ERR_INVALID, "no frames");
+  LPT_HIP(c, hipSetDevice(c->device));
+  // the previous call's events and pinned staging must be free again
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  c->evUsed = 0;
+  c->haveTiming = false;
+  LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, 2 * sizeof(unsigned long long), c->stream));
+  LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
+  if (c->pipeline == LPT_PIPELINE_MEGAKERNEL) {
+    for (int f = 0; f < n_frames; ++f) {
+      rc = render_frame_mega(c, ubos[f]);
+      if (rc) return rc;
+    }
+  } else {
+    const int fif = auto_frames_in_flight(c);
+    for (int f = 0; f < n_frames; f += fif) {
+      int nb = std::min(fif, n_frames - f);
+      if (f > 0) LPT_HIP(c, hipStreamSynchronize(c->stream));  // pinned ubo staging is reused
+      rc = render_batch_wavefront(c, ubos + f, nb);
+      if (rc) return rc;
+    }
+  }
+  LPT_HIP(c, hipEventRecord(c->evStop, c->stream));
+  c->lastFrames = (uint64_t)n_frames;
+  c->haveTiming = true;
+  return LPT_OK;
+}
+
+int lpt_render_frame(lpt_ctx* c, const lpt_ubo* ubo) { return lpt_render_frames(c, ubo, 1); }
+
+int lpt_synchronize(lpt_ctx* c) {
+  if (!c) return LPT_ERR_INVALID;
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  return LPT_OK;
+}
+
+int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
+  if (!c || !out) return LPT_ERR_INVALID;
+  std::memset(out, 0, sizeof *out);
+  if (!c->haveTiming) return fail(c, LPT_ERR_INVALID, "nothing rendered yet");
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  unsigned long long totals[2] = {0, 0};
+  LPT_HIP(c, hipMemcpy(totals, c->dTotals, sizeof totals, hipMemcpyDeviceToHost));
+  out->paths = totals[0];
+  out->segments = totals[1];
+  out->frames = c->lastFrames;
+  float ms = 0.0f;
+  LPT_HIP(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
+  out->device_ms = ms;
+  double ext = 0.0;
+  for (size_t i = 0; i + 1 < c->evUsed; i += 2) {
+    LPT_HIP(c, hipEventElapsedTime(&ms, c->evPool[i], c->evPool[i + 1]));
+    ext += ms;
+  }
+  out->extend_ms = ext;
+  out->extend_launches = (uint32_t)(c->evUsed / 2);
+  return LPT_OK;
+}
+
+int lpt_read_accum(lpt_ctx* c, float* dst) {
+  if (!c || !dst) return LPT_ERR_INVALID;
+  if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
+  const Partition& P = c->part;
+  dim3 blk(16, 16), grd((P.W + 15) / 16, (P.H + 15) / 16);
+  hipLaunchKernelGGL(k_unpermute, grd, blk, 0, c->stream, P, c->dAccum, c->dImage);
+  LPT_HIP(c, hipGetLastError());
+  LPT_HIP(c, hipMemcpyAsync(dst, c->dImage, (size_t)P.W * P.H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  return LPT_OK;
+}
+
+int lpt_owned_slots(lpt_ctx* c, uint64_t* n) {
+  if (!c || !n) return LPT_ERR_INVALID;
+  if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
+  *n = c->part.nSlots;
+  return LPT_OK;
+}
+
+int lpt_owned_accum_device(lpt_ctx* c, void** p) {
+  if (!c || !p) return LPT_ERR_INVALID;
+  if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
+  *p = c->dAccum;
+  return LPT_OK;
+}
+
+int lpt_assemble_gathered(lpt_ctx* c, const void* gathered, int n_ranks, void* image) {
+  if (!c || !gathered || !image) return LPT_ERR_INVALID;
+  if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
+  if (n_ranks != c->part.nRanks) return fail(c, LPT_ERR_INVALID, "n_ranks differs from the partition");
+  const Partition& P = c->part;
+  dim3 blk(16, 16), grd((P.W + 15) / 16, (P.H + 15) / 16);
+  hipLaunchKernelGGL(k_assemble, grd, blk, 0, c->stream, P, (const float4*)gathered, (float4*)image);
+  LPT_HIP(c, hipGetLastError());
+  return LPT_OK;
+}
+
+int lpt_resolve(lpt_ctx* c, float inv_sample_count, float* dst) {
+  if (!c || !dst) return LPT_ERR_INVALID;
+  if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
+  const Partition& P = c->part;
+  dim3 blk(16, 16), grd((P.W + 15) / 16, (P.H + 15) / 16);
+  hipLaunchKernelGGL(k_resolve, grd, blk, 0, c->stream, P, c->dAccum, inv_sample_count, c->dImage);
+  LPT_HIP(c, hipGetLastError());
+  LPT_HIP(c, hipMemcpyAsync(dst, c->dImage, (size_t)P.W * P.H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  return LPT_OK;
+}
+
+int lpt_debug_math(lpt_ctx* c, int op, const float* a, const float* b, float* out, uint32_t n) {
+  if (!c || !a || !out || n == 0) return LPT_ERR_INVALID;
+  LPT_HIP(c, hipSetDevice(c->device));
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  LPT_HIP(c, hipMalloc(&da, n * sizeof(float)));
+  LPT_HIP(c, hipMalloc(&dout, n * sizeof(float)));
+  LPT_HIP(c, hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
+  if (b) {
+    LPT_HIP(c, hipMalloc(&db, n * sizeof(float)));
+    LPT_HIP(c, hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, da, db, dout, n);
+  LPT_HIP(c, hipGetLastError());
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  LPT_HIP(c, hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost));
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  return LPT_OK;
+}
+
+int lpt_debug_intersect(lpt_ctx* c, const float* o, const float* d, uint32_t n, float* t, uint32_t* obj,
+                        uint32_t* prim) {
+  if (!c || !o || !d || !t || !obj || !prim || n == 0) return LPT_ERR_INVALID;
+  if (!c->sceneLoaded) return fail(c, LPT_ERR_INVALID, "no scene uploaded");
+  LPT_HIP(c, hipSetDevice(c->device));
+  float *dO = nullptr, *dD = nullptr, *dT = nullptr;
+  uint32_t *dObj = nullptr, *dPrim = nullptr;
+  LPT_HIP(c, hipMalloc(&dO, 3 * (size_t)n * sizeof(float)));
+  LPT_HIP(c, hipMalloc(&dD, 3 * (size_t)n * sizeof(float)));
+  LPT_HIP(c, hipMalloc(&dT, n * sizeof(float)));
+  LPT_HIP(c, hipMalloc(&dObj, n * sizeof(uint32_t)));
+  LPT_HIP(c, hipMalloc(&dPrim, n * sizeof(uint32_t)));
+  LPT_HIP(c, hipMemcpy(dO, o, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  LPT_HIP(c, hipMemcpy(dD, d, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  dim3 grd((n + kBlock - 1) / kBlock), blk(kBlock);
+  DScene sc = device_scene(c);
+  if (c->stackNeed <= 16) hipLaunchKernelGGL(k_debug_intersect<16>, grd, blk, 0, c->stream, sc, dO, dD, n, dT, dObj, dPrim);
+  else if (c->stackNeed <= 32) hipLaunchKernelGGL(k_debug_intersect<32>, grd, blk, 0, c->stream, sc, dO, dD, n, dT, dObj, dPrim);
+  else hipLaunchKernelGGL(k_debug_intersect<64>, grd, blk, 0, c->stream, sc, dO, dD, n, dT, dObj, dPrim);
+  LPT_HIP(c, hipGetLastError());
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  LPT_HIP(c, hipMemcpy(t, dT, n * sizeof(float), hipMemcpyDeviceToHost));
+  LPT_HIP(c, hipMemcpy(obj, dObj, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  LPT_HIP(c, hipMemcpy(prim, dPrim, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  (void)hipFree(dO);
+  (void)hipFree(dD);
+  (void)hipFree(dT);
+  (void)hipFree(dObj);
+  (void)hipFree(dPrim);
+  return LPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Host BVH builders under the names the reference's scene converter uses
+// (lsg::bvh::BVHBuilder / SplitBVHBuilder, src/PTSceneConverter.cpp:97-101,134-138).
+// Both produce a binary tree in depth-first order: node 0 is the root, a node's
+// first child follows it directly.  Leaves hold a half-open range into
+// getPrimitiveIndices().
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "lsg_min.hpp"
+
+namespace lsg {
+namespace bvh {
+
+struct uvec2 {
+  uint32_t x = 0, y = 0;
+};
+
+template <typename T>
+struct Node {
+  AABB<T> bounds;
+  bool is_leaf = false;
+  uvec2 child_indices;  // inner: child node indices; leaf: [first, last) into the primitive order
+};
+
+template <typename T>
+class BVH {
+ public:
+  const std::vector<Node<T>>& getNodes() const { return nodes_; }
+  const std::vector<uint32_t>& getPrimitiveIndices() const { return primitiveIndices_; }
+  const AABB<T>& getBounds() const { return bounds_; }
+  uint32_t depth() const;
+
+  std::vector<Node<T>> nodes_;
+  std::vector<uint32_t> primitiveIndices_;
+  AABB<T> bounds_;
+};
+
+struct BuildOptions {
+  uint32_t maxLeafSize = 4;     // primitives per leaf
+  uint32_t bins = 16;           // SAH bins per axis
+  float traversalCost = 1.0f;   // relative to one primitive test
+  // Spatial splits (SplitBVHBuilder only): a spatial split is tried when the overlap of
+  // the best object split exceeds this fraction of the root's surface area.
+  float splitAlpha = 1e-5f;
+  bool spatialSplits = true;
+};
+
+// Binned surface-area-heuristic build over axis-aligned boxes (object splits only).
+template <typename T>
+class BVHBuilder {
+ public:
+  explicit BVHBuilder(BuildOptions opt = {}) : opt_(opt) {}
+  Ref<BVH<T>> process(const std::vector<AABB<T>>& boxes);
+
+ private:
+  BuildOptions opt_;
+};
+
+// SAH build over triangles that may also split triangles spatially (Stich et al.,
+// "Spatial Splits in Bounding Volume Hierarchies", 2009): a triangle straddling a split
+// plane is referenced from both sides, so getPrimitiveIndices() may repeat indices.
+template <typename T>
+class SplitBVHBuilder {
+ public:
+  explicit SplitBVHBuilder(BuildOptions opt = {}) : opt_(opt) {}
+  Ref<BVH<T>> process(const Ref<TriangleAccessor<vec3>>& triangles);
+
+ private:
+  BuildOptions opt_;
+};
+
+}  // namespace bvh
+}  // namespace lsg

@@ -1,0 +1,173 @@
+#include "pt_scene_converter.hpp"
+
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+namespace {
+
+constexpr uint32_t kNoTexture = 0xFFFFFFFFu;
+
+GPUBVHNode packNode(const lsg::bvh::Node<float>& n) {
+  GPUBVHNode g;
+  std::memset(&g, 0, sizeof g);
+  g.minCorner[0] = n.bounds.min().x; g.minCorner[1] = n.bounds.min().y; g.minCorner[2] = n.bounds.min().z;
+  g.maxCorner[0] = n.bounds.max().x; g.maxCorner[1] = n.bounds.max().y; g.maxCorner[2] = n.bounds.max().z;
+  g.isLeaf = n.is_leaf ? 1u : 0u;
+  g.indices[0] = n.child_indices.x;
+  g.indices[1] = n.child_indices.y;
+  return g;
+}
+
+GPUVertex packVertex(const lsg::vec3& p, const lsg::vec3& n, const lsg::vec2& uv) {
+  GPUVertex v;
+  std::memset(&v, 0, sizeof v);
+  v.position[0] = p.x; v.position[1] = p.y; v.position[2] = p.z;
+  v.normal[0] = n.x; v.normal[1] = n.y; v.normal[2] = n.z;
+  v.uv[0] = uv.x; v.uv[1] = uv.y;
+  return v;
+}
+
+}  // namespace
+
+PTSceneConverter::PTSceneConverter(lpt_ctx* device) : device_(device) {}
+
+void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
+  reset();
+  if (!scene) throw std::runtime_error("PTSceneConverter::loadScene: null scene");
+
+  std::vector<lsg::AABB<float>> worldBoxes;       // one per sub-mesh instance
+  std::vector<GPUObjectData> pendingObjects;      // in scene-graph order, before BVH ordering
+
+  auto visit = [&](const lsg::Ref<lsg::Object>& object) -> bool {
+    lsg::mat4 world;  // identity when the object carries no transform
+    if (auto tr = object->getComponent<lsg::Transform>()) world = tr->worldMatrix();
+
+    if (object->getComponent<lsg::PerspectiveCamera>()) cameras_.push_back(object);
+
+    auto mesh = object->getComponent<lsg::Mesh>();
+    if (!mesh) return true;
+    if (verbose_) std::cout << "Building BVH for object " << object->name() << "..." << std::endl;
+
+    for (const auto& sub : mesh->subMeshes()) {
+      auto material = lsg::dynamicRefCast<lsg::MetallicRoughnessMaterial>(sub->material());
+      if (!material) {
+        if (verbose_) std::cout << "Unknown material. Skipping submesh." << std::endl;
+        continue;
+      }
+      if (material->baseColorTex() || material->emissiveTex() || material->metallicRoughnessTex() ||
+          material->transmissionTexture() || material->normalTex())
+        throw std::runtime_error("PTSceneConverter: textured materials are not supported (object '" + object->name() + "')");
+
+      GPUObjectData od;
+      std::memset(&od, 0, sizeof od);
+      const lsg::mat4 inv = lsg::inverse(world);
+      std::memcpy(od.worldMatrix, world.m, sizeof od.worldMatrix);
+      std::memcpy(od.worldMatrixInverse, inv.m, sizeof od.worldMatrixInverse);
+      const lsg::vec4& bc = material->baseColorFactor();
+      od.baseColorFactor[0] = bc.x; od.baseColorFactor[1] = bc.y; od.baseColorFactor[2] = bc.z; od.baseColorFactor[3] = bc.w;
+      const lsg::vec3& em = material->emissiveFactor();
+      od.emissionFactor[0] = em.x; od.emissionFactor[1] = em.y; od.emissionFactor[2] = em.z;
+      od.metallicFactor = material->metallicFactor();
+      od.roughnessFactor = material->roughnessFactor();
+      od.transmissionFactor = material->transmissionFactor();
+      od.ior = material->ior();
+      od.colorTexture = od.emissionTexture = od.metallicRoughnessTexture = od.transmissionTexture = od.normalTexture = kNoTexture;
+      // element indices, not byte offsets (src/PTSceneConverter.cpp:87-88)
+      od.bvhOffset = (uint32_t)meshBVHNodes_.size();
+      od.verticesOffset = (uint32_t)vertices_.size();
+
+      auto geometry = sub->geometry();
+      auto posAcc = geometry->getTrianglePositionAccessor();
+      auto nrmAcc = geometry->getTriangleNormalAccessor();
+      auto uvAcc = geometry->hasUv(0u) ? geometry->getTriangleUVAccessor(0u) : nullptr;
+      const uint32_t nTris = (uint32_t)posAcc->count();
+
+      // mesh tree + triangle order of its leaves
+      std::vector<uint32_t> order;
+      lsg::AABB<float> localBounds;
+      if (meshBuilder_ == MeshBuilder::LBVH) {
+        if (!device_) throw std::runtime_error("PTSceneConverter: the LBVH builder needs a device context");
+        std::vector<float> corners(9 * (size_t)nTris);
+        for (uint32_t t = 0; t < nTris; ++t) {
+          auto T = (*posAcc)[t];
+          const lsg::vec3 c[3] = {T.a(), T.b(), T.c()};
+          for (int k = 0; k < 3; ++k) {
+            corners[9 * (size_t)t + 3 * k + 0] = c[k].x;
+            corners[9 * (size_t)t + 3 * k + 1] = c[k].y;
+            corners[9 * (size_t)t + 3 * k + 2] = c[k].z;
+            localBounds.expand(c[k]);
+          }
+        }
+        std::vector<GPUBVHNode> nodes(nTris ? 2 * (size_t)nTris : 1);
+        order.resize(nTris);
+        uint32_t nNodes = 0;
+        int rc = lpt_build_mesh_bvh(device_, LPT_BVH_LBVH, corners.data(), nTris, nodes.data(), &nNodes, order.data());
+        if (rc != LPT_OK) throw std::runtime_error(std::string("lpt_build_mesh_bvh: ") + lpt_last_error(device_));
+        meshBVHNodes_.insert(meshBVHNodes_.end(), nodes.begin(), nodes.begin() + nNodes);
+      } else {
+        lsg::bvh::BuildOptions opt = buildOptions_;
+        opt.spatialSplits = meshBuilder_ == MeshBuilder::SplitBVH;
+        lsg::bvh::SplitBVHBuilder<float> builder(opt);
+        auto bvh = builder.process(posAcc);
+        for (const auto& node : bvh->getNodes()) meshBVHNodes_.push_back(packNode(node));
+        order = bvh->getPrimitiveIndices();
+        localBounds = bvh->getBounds();
+      }
+
+      // de-indexed, interleaved vertices in leaf order (src/PTSceneConverter.cpp:105-120)
+      for (uint32_t idx : order) {
+        auto P = (*posAcc)[idx];
+        auto N = (*nrmAcc)[idx];
+        if (uvAcc) {
+          auto U = (*uvAcc)[idx];
+          vertices_.push_back(packVertex(P.a(), N.a(), U.a()));
+          vertices_.push_back(packVertex(P.b(), N.b(), U.b()));
+          vertices_.push_back(packVertex(P.c(), N.c(), U.c()));
+        } else {
+          vertices_.push_back(packVertex(P.a(), N.a(), {}));
+          vertices_.push_back(packVertex(P.b(), N.b(), {}));
+          vertices_.push_back(packVertex(P.c(), N.c(), {}));
+        }
+      }
+      worldBoxes.push_back(localBounds.transform(world));
+      pendingObjects.push_back(od);
+    }
+    return true;
+  };
+  for (const auto& root : scene->children()) root->traverseDown(visit);
+
+  if (pendingObjects.empty()) throw std::runtime_error("PTSceneConverter: the scene contains no renderable geometry");
+
+  // object tree; objects are stored in the order of its leaves (src/PTSceneConverter.cpp:134-142)
+  lsg::bvh::BuildOptions topOpt = buildOptions_;
+  topOpt.maxLeafSize = 1;
+  lsg::bvh::BVHBuilder<float> topBuilder(topOpt);
+  auto top = topBuilder.process(worldBoxes);
+  for (const auto& node : top->getNodes()) objectBVHNodes_.push_back(packNode(node));
+  for (uint32_t idx : top->getPrimitiveIndices()) objectData_.push_back(pendingObjects[idx]);
+
+  copyToGPU();
+}
+
+void PTSceneConverter::copyToGPU() {
+  if (!device_) return;
+  int rc = lpt_upload_scene(device_, objectData_.data(), (uint32_t)objectData_.size(), objectBVHNodes_.data(),
+                            (uint32_t)objectBVHNodes_.size(), vertices_.data(), (uint32_t)vertices_.size(),
+                            meshBVHNodes_.data(), (uint32_t)meshBVHNodes_.size());
+  if (rc != LPT_OK) throw std::runtime_error(std::string("lpt_upload_scene: ") + lpt_last_error(device_));
+}
+
+const std::vector<lsg::Ref<lsg::Object>>& PTSceneConverter::getCameras() const { return cameras_; }
+const std::vector<GPUObjectData>& PTSceneConverter::getObjectDataBuffer() const { return objectData_; }
+const std::vector<GPUBVHNode>& PTSceneConverter::getObjectBvhNodesBuffer() const { return objectBVHNodes_; }
+const std::vector<GPUVertex>& PTSceneConverter::getVerticesBuffer() const { return vertices_; }
+const std::vector<GPUBVHNode>& PTSceneConverter::getMeshBvhNodesBuffer() const { return meshBVHNodes_; }
+
+void PTSceneConverter::reset() {
+  cameras_.clear();
+  objectData_.clear();
+  objectBVHNodes_.clear();
+  vertices_.clear();
+  meshBVHNodes_.clear();
+}

@@ -1,0 +1,76 @@
+// RendererPT: host driver of the path-tracing compute path, with the public methods of
+// the reference class (include/RendererPT.h:13-19) and its per-frame contract
+// (src/RendererPT.cpp:574-612): a camera change restarts accumulation, every frame gets
+// a fresh pair of seeds and adds one sample per pixel.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <vector>
+
+#include "glibc_rand.hpp"
+#include "pt_scene_converter.hpp"
+#include "renderer_core.hpp"
+
+class RendererPT : public RendererCore {
+ public:
+  RendererPT(const cppglfw::Window& window, const RendererConfiguration& configuration);
+
+  // May run on another thread than drawFrame (src/Main.cpp:45); drawFrame does nothing
+  // until loading has finished.
+  void loadScene(const lsg::Ref<lsg::Scene>& scene) override;
+
+  void drawFrame() override;
+
+  // ---- additions for headless, reproducible use -------------------------------------
+  // n consecutive frames with the same per-frame contract, submitted as one batch.
+  void drawFrames(uint32_t n);
+  // Seed of the frame-seed generator; the reference uses srand(time(0)) (src/RendererPT.cpp:13).
+  void setSeed(uint32_t seed) { rand_.srand(seed); }
+  // MAX_TRACE_DEPTH and the BSDF family are compile-time choices in the reference shader
+  // (shaders/path_tracing.comp:20,22).
+  void setMaxTraceDepth(int bounces);
+  void setBsdfMode(int mode);
+  void setPipeline(int pipeline, int framesInFlight = 0);
+  void setMeshBuilder(PTSceneConverter::MeshBuilder b) { sceneConverter_.setMeshBuilder(b); }
+  void setVerbose(bool v) { verbose_ = v; sceneConverter_.setVerbose(v); }
+  // Accumulated radiance, width*height RGBA32F, alpha = number of samples; row 0 first.
+  void readAccumulation(std::vector<float>& rgba);
+  // Display image of shaders/tex_to_quad.frag (tone-mapped, gamma-corrected, y-flipped).
+  void resolve(std::vector<float>& rgba);
+  // Samples accumulated per pixel so far.
+  uint32_t samples() const { return sampleCount - 1; }
+  const PTSceneConverter& sceneConverter() const { return sceneConverter_; }
+  const lsg::Ref<lsg::Transform>& cameraTransform() const { return selectedCameraTransform_; }
+
+ protected:
+  void initializeAccumulationTexture();
+  void onSwapChainRecreate() override;
+  void preDraw() override;
+  void postDraw() override;
+  void submitFrame() override;
+
+ private:
+  // include/RendererPT.h:51-61; std140 block of shaders/path_tracing.comp:83-87
+  using PathTracerUBO = lpt_ubo;
+  void applyOptions();
+
+  PathTracerUBO ubo_;
+  std::vector<PathTracerUBO> pending_;
+
+  uint32_t sampleCount = 1;
+  float invSampleCount = 1;
+
+  int maxTraceDepth_ = 10;
+  int bsdfMode_ = LPT_BSDF_HEITZ;
+  int pipeline_ = LPT_PIPELINE_WAVEFRONT;
+  int framesInFlight_ = 0;
+  bool verbose_ = false;
+  bool batching_ = false;
+
+  GlibcRand rand_;
+  std::chrono::time_point<std::chrono::high_resolution_clock> startTime_;
+
+  std::atomic<bool> sceneLoaded_{false};
+  lsg::Ref<lsg::Transform> selectedCameraTransform_;
+  PTSceneConverter sceneConverter_;
+};
