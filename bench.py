@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the RendererPT compute path on MI355X.
+
+Metric (BASELINE.json): Msamples/s at 1920x1080, 8-bounce Cornell box, where a sample is one
+ray segment actually traced (one iteration of traceRay's loop, shaders/path_tracing.comp:216-324).
+`value` counts traced segments only; the nominal figure W*H*spp*bounces/t is reported beside it.
+
+A step renders `spp_per_step` frames (one sample per pixel each) of the whole image; with N GPUs the
+image is cut into tiles dealt round-robin to the ranks and spp_per_step grows with N, so each GPU
+traces the same number of camera paths per step at every N (weak scaling).  No collective runs in
+the timed region; the single gather of the HDR tile buffers happens after it and is timed apart.
+
+  python bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+
+
+class _DeviceArray:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it."""
+
+    def __init__(self, ptr, n_floats):
+        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False), "version": 3}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=8, help="frames per step and per GPU")
+    ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_box.gltf"))
+    ap.add_argument("--builder", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0: automatic)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, ubos, width, height, bounces, frames):
+    """Times the CPU oracle (OpenMP over pixels) on a bounded sample of the same workload and returns
+    (baseline dict, oracle work counters of the sample)."""
+    from oracle import binding as O
+    osc = O.OracleScene(scene.objects, scene.object_bvh, scene.vertices, scene.mesh_bvh)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    if frames <= 0:
+        t0 = time.perf_counter()
+        O.render_frames(osc, ubos[:1], width, height, bounces, threads=threads)
+        one = time.perf_counter() - t0
+        frames = int(max(1, min(len(ubos), 15.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    _, st = O.render_frames(osc, ubos[:frames], width, height, bounces, threads=threads)
+    dt = time.perf_counter() - t0
+    base = {"value": st["segments"] / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} frame(s) of {width}x{height}, {bounces} bounces, same scene and seeds "
+                      f"({st['segments']} segments in {dt:.2f} s)"}
+    return base, st
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        print(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+
+    import logipathtracer_amd as L
+    dev = L.Device(local_rank)
+    scene = L.Scene(args.scene, builder=args.builder if args.builder != L.BUILDER_LBVH else L.BUILDER_LBVH,
+                    device=dev if args.builder == L.BUILDER_LBVH else None)
+    dev.upload_scene(scene)
+    dev.resize(args.width, args.height)
+    if world > 1:
+        dev.set_partition(args.tile, args.tile, rank, world)
+    dev.set_options(args.bounces, L.BSDF_HEITZ, args.pipeline, args.frames_in_flight)
+
+    spp_step = args.spp_per_step * world
+    n_steps_total = args.warmup + args.steps
+    ubos = L.frame_ubos(scene.camera_world, scene.fov_y, spp_step * n_steps_total, seed=0x5EED)
+
+    def barrier():
+        dev.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_stats = []
+
+    def run_step(i):
+        dev.render_frames(ubos[i * spp_step:(i + 1) * spp_step])
+
+    for i in range(args.warmup):
+        run_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    seg = paths = 0
+    ext_ms = 0.0
+    ext_launches = 0
+    dev_ms = 0.0
+    for i in range(args.warmup, n_steps_total):
+        run_step(i)
+        st = dev.stats()  # waits for the step; counters and HIP-event times of this step
+        seg += st.segments
+        paths += st.paths
+        ext_ms += st.extend_ms
+        ext_launches += st.extend_launches
+        dev_ms += st.device_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # ---- after the timed region: gather the HDR tile buffers once (RCCL over xGMI) ----
+    gather_ms = None
+    if world > 1:
+        n_floats = dev.owned_slots() * 4
+        mine = torch.as_tensor(_DeviceArray(dev.owned_accum_device(), n_floats), device=f"cuda:{local_rank}")
+        gathered = torch.empty(world * n_floats, dtype=torch.float32, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(gathered, mine)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        image = torch.empty(args.height * args.width * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+        dev.assemble_gathered(gathered.data_ptr(), world, image.data_ptr())
+        dev.synchronize()
+
+    if world > 1:
+        t = torch.tensor([elapsed, float(seg), float(paths), ext_ms, float(ext_launches)], dtype=torch.float64,
+                         device=f"cuda:{local_rank}")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        seg_total, paths_total = float(tsum[1]), float(tsum[2])
+    else:
+        seg_total, paths_total = float(seg), float(paths)
+
+    if rank == 0:
+        frames_total = spp_step * args.steps
+        nominal = args.width * args.height * frames_total * args.bounces
+        result = {
+            "metric": "Msamples/s (ray segments traced/s) at 1920x1080, 8-bounce Cornell box",
+            "value": seg_total / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic seeds on the reference's cornell_box.gltf asset; no dataset",
+            "config": {
+                "workload": f"{os.path.basename(args.scene)} {args.width}x{args.height}, {args.bounces} bounces, "
+                            f"Heitz BSDF, {spp_step} spp per step ({args.spp_per_step} per GPU)",
+                "spp_per_step": spp_step, "tile": args.tile if world > 1 else None,
+                "builder": ["split_bvh", "binned_sah", "lbvh_gpu"][args.builder],
+                "pipeline": ["wavefront", "megakernel"][args.pipeline],
+            },
+            "nominal_msamples_per_s": nominal / elapsed / 1e6,
+            "traced_segments": seg_total,
+            "camera_paths": paths_total,
+            "mean_path_length": seg_total / max(paths_total, 1.0),
+            "device_ms_rank0": dev_ms,
+            "gather_ms": gather_ms,
+        }
+        cpu = None
+        counters = None
+        if not args.no_cpu_baseline:
+            cpu, counters = cpu_baseline(scene, ubos, args.width, args.height, args.bounces, args.cpu_frames)
+        result["cpu_baseline"] = cpu
+        # roofline of the dominant kernel (k_extend): algorithmic bytes per traced segment =
+        # 64 B per inner node visited (both child boxes) ... stated in interchange terms as
+        # 48 B per node fetched + 36 B per triangle tested + 24 B ray in + 12 B hit out.
+        if counters and ext_ms > 0:
+            n_node = (counters["boxTests"] + counters["rootVisits"]) / counters["segments"]
+            n_tri = counters["triTests"] / counters["segments"]
+            bytes_per_seg = 48.0 * n_node + 36.0 * n_tri + 24.0 + 12.0
+            achieved = bytes_per_seg * float(seg) / (ext_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            result["roofline"] = {
+                "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bytes_per_segment": bytes_per_seg, "nodes_per_segment": n_node, "tris_per_segment": n_tri,
+                "avg_launch_ms": ext_ms / max(ext_launches, 1), "launches": ext_launches,
+                "segments_per_launch": float(seg) / max(ext_launches, 1),
+            }
+        else:
+            result["roofline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    dev.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
