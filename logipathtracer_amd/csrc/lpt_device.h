@@ -334,6 +334,7 @@ struct Partition {
   int rank, nRanks;
   int nLocalTiles;   // ceil(tilesX*tilesY / nRanks), equal on every rank
   uint32_t nSlots;   // nLocalTiles * tileW * tileH
+  int dense;         // 1 if every slot of this rank is a pixel inside the image
 };
 
 __device__ __forceinline__ bool slot_to_pixel(const Partition& P, uint32_t slot, int& x, int& y) {

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "lpt_device.h"
+#include "lpt_extend.h"
 #include "lpt_internal.h"
 
 #pragma clang fp contract(off)
@@ -45,16 +46,25 @@ struct Queue {
   float4* a;  // gathered radiance.rgb, rng.y (bits)
 };
 
-// Wave-level append: every lane with `active` gets a distinct slot of a queue whose
-// fill count lives in *counter; one atomic per wave.
-__device__ __forceinline__ uint32_t wave_append(bool active, uint32_t* counter) {
-  unsigned long long ballot = __ballot(active);
-  uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-  uint32_t total = (uint32_t)__popcll(ballot);
-  uint32_t base = 0;
-  if (active && below == 0u) base = atomicAdd(counter, total);
-  int leader = ballot ? (__ffsll((long long)ballot) - 1) : 0;
-  base = (uint32_t)__shfl((int)base, leader);
+// Block-level append: every thread with `active` gets a distinct slot of a queue whose fill
+// count lives in *counter.  One atomic per block: a single counter word sustains only some
+// tens of atomics per microsecond, so per-wave atomics would bound the kernel.
+// Must be called by all threads of the block.
+__device__ __forceinline__ uint32_t block_append(bool active, uint32_t* counter, uint32_t* lds /* [kBlock/64 + 1] */) {
+  const unsigned long long ballot = __ballot(active);
+  const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+  const uint32_t wave = threadIdx.x >> 6;
+  __syncthreads();  // the previous call's readers are done with lds
+  if ((threadIdx.x & 63u) == 0u) lds[wave] = (uint32_t)__popcll(ballot);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < kBlock / 64; ++w) total += lds[w];
+    lds[kBlock / 64] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = lds[kBlock / 64];
+  for (uint32_t w = 0; w < wave; ++w) base += lds[w];
   return base + below;
 }
 
@@ -68,8 +78,11 @@ __device__ __forceinline__ void store_path(const Queue& q, uint32_t slot, const 
 // ---- wavefront kernels ---------------------------------------------------------------
 
 // Camera rays for `nFrames` frames of the owned pixels (path id = frame*nSlots + slot).
+// `dense` = every slot is a pixel of the image: path pid goes to queue slot pid and the host
+// sets the queue count; otherwise slots outside the image are skipped by compaction.
 __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
-                                                     Queue q, uint32_t* count) {
+                                                     Queue q, uint32_t* count, int dense) {
+  __shared__ uint32_t lds[kBlock / 64 + 1];
   const uint32_t total = nFrames * P.nSlots;
   for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
     uint32_t pid = base + threadIdx.x;
@@ -83,23 +96,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
         active = true;
       }
     }
-    uint32_t dst = wave_append(active, count);
+    uint32_t dst = dense ? pid : block_append(active, count, lds);
     if (active) store_path(q, dst, p, pid);
   }
 }
 
-// Closest hit for every queued ray; the traversal stack lives in LDS, one column per thread.
+// Closest hit for every queued ray: persistent waves, node stack in LDS (one column per
+// thread), rays handed out through `cursor` (zeroed before the launch).  See lpt_extend.h.
 template <int S>
 __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
                                                    const float4* __restrict__ qd, const uint32_t* __restrict__ count,
-                                                   float4* __restrict__ hits) {
+                                                   float4* __restrict__ hits, uint32_t* cursor) {
   __shared__ uint32_t stack[S * kBlock];
-  const uint32_t n = *count;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    float4 o = qo[i], d = qd[i];
-    Hit h = intersect_scene(sc, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, &stack[threadIdx.x], kBlock);
-    hits[i] = make_float4(h.t, as_float(h.obj), as_float(h.prim), 0.0f);
-  }
+  extend_persistent<S, kBlock>(sc, qo, qd, *count, hits, cursor, stack);
 }
 
 // Shades every queued hit, samples the next direction, applies Russian roulette; paths
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
                                                   const uint32_t* __restrict__ countIn, Queue out, uint32_t* countOut,
                                                   float4* __restrict__ samples, uint32_t bounce, uint32_t maxBounces,
                                                   int bsdfMode) {
+  __shared__ uint32_t lds[kBlock / 64 + 1];
   const uint32_t n = *countIn;
   for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
     uint32_t i = base + threadIdx.x;
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
       alive = shade_hit(sc, p, hit, bounce, maxBounces, bsdfMode, s);
       if (!alive) samples[pid] = make_float4(s.x, s.y, s.z, 0.0f);
     }
-    uint32_t dst = wave_append(alive, countOut);
+    uint32_t dst = block_append(alive, countOut, lds);
     if (alive) store_path(out, dst, p, pid);
   }
 }
@@ -325,6 +335,7 @@ struct lpt_ctx {
   int bsdfMode = LPT_BSDF_HEITZ;
   int pipeline = LPT_PIPELINE_WAVEFRONT;
   int framesInFlight = 0;
+  int extendBlocksPerCU = 6;
 
   // wavefront pool
   size_t poolPaths = 0;
@@ -333,7 +344,7 @@ struct lpt_ctx {
   Queue queues[2]{};
   float4* dHits = nullptr;
   float4* dSamples = nullptr;
-  uint32_t* dCounts = nullptr;
+  uint32_t* dCounts = nullptr;   // [poolBounces] queue fills, then [poolBounces] ray cursors of k_extend
   lpt_ubo* dUbos = nullptr;
   lpt_ubo* hUbos = nullptr;  // pinned staging
   int ubosCap = 0;
@@ -510,7 +521,7 @@ int ensure_pool(lpt_ctx* c, int frames) {
   }
   if (c->maxBounces + 1 > c->poolBounces) {
     dfree(c->dCounts);
-    LPT_HIP(c, hipMalloc(&c->dCounts, (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
+    LPT_HIP(c, hipMalloc(&c->dCounts, 2 * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
     c->poolBounces = c->maxBounces + 1;
   }
   if (frames > c->ubosCap) {
@@ -518,7 +529,7 @@ int ensure_pool(lpt_ctx* c, int frames) {
     if (c->hUbos) (void)hipHostFree(c->hUbos);
     c->hUbos = nullptr;
     LPT_HIP(c, hipMalloc(&c->dUbos, (size_t)frames * sizeof(lpt_ubo)));
-    LPT_HIP(c, hipHostMalloc(&c->hUbos, (size_t)frames * sizeof(lpt_ubo)));
+    LPT_HIP(c, hipHostMalloc(&c->hUbos, ((size_t)frames + 1) * sizeof(lpt_ubo)));
     c->ubosCap = frames;
   }
   return 0;
@@ -531,18 +542,18 @@ int grid_for(const lpt_ctx* c, size_t items, int blocksPerCU) {
 }
 
 template <int S>
-int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, size_t maxItems) {
-  // LDS bounds residency: S*1 KiB per block of 256 threads, 160 KiB per CU
-  int perCU = std::max(1, std::min(8, 160 / S));
+int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
+  // persistent grid: LDS bounds residency (S KiB per block of 256 threads, 160 KiB per CU)
+  int perCU = std::max(1, std::min(c->extendBlocksPerCU, 160 / S));
   hipLaunchKernelGGL(k_extend<S>, dim3(grid_for(c, maxItems, perCU)), dim3(kBlock), 0, c->stream, device_scene(c), q.o,
-                     q.d, count, c->dHits);
+                     q.d, count, c->dHits, cursor);
   return 0;
 }
 
-int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, size_t maxItems) {
-  if (c->stackNeed <= 16) return launch_extend<16>(c, q, count, maxItems);
-  if (c->stackNeed <= 32) return launch_extend<32>(c, q, count, maxItems);
-  return launch_extend<64>(c, q, count, maxItems);
+int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
+  if (c->stackNeed <= 16) return launch_extend<16>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 32) return launch_extend<32>(c, q, count, cursor, maxItems);
+  return launch_extend<64>(c, q, count, cursor, maxItems);
 }
 
 int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
@@ -552,16 +563,23 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   const uint32_t nB = (uint32_t)c->maxBounces;
   std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
   LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (size_t)(nB + 1) * sizeof(uint32_t), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, 2 * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
+  uint32_t* cursors = c->dCounts + c->poolBounces;
+  const int dense = c->part.dense ? 1 : 0;
+  if (dense) {
+    // every slot is a pixel: the first queue is filled in path-id order, its count is known here
+    c->hUbos[frames].seed[0] = (uint32_t)paths;  // staging word behind the frame blocks
+    LPT_HIP(c, hipMemcpyAsync(c->dCounts, &c->hUbos[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  }
   hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
-                     (uint32_t)frames, c->queues[0], c->dCounts);
+                     (uint32_t)frames, c->queues[0], c->dCounts, dense);
   rc = ensure_events(c, c->evUsed + 2 * (size_t)nB);
   if (rc) return rc;
   for (uint32_t b = 0; b < nB; ++b) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-    dispatch_extend(c, in, c->dCounts + b, paths);
+    dispatch_extend(c, in, c->dCounts + b, cursors + b, paths);
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
                        c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
@@ -602,6 +620,7 @@ int set_partition(lpt_ctx* c, int W, int H, int tileW, int tileH, int rank, int 
   size_t slots = (size_t)P.nLocalTiles * tileW * tileH;
   if (slots >= (1ull << 31)) return fail(c, LPT_ERR_INVALID, "image too large for one context");
   P.nSlots = (uint32_t)slots;
+  P.dense = (W % tileW == 0 && H % tileH == 0 && (P.tilesX * P.tilesY) % nRanks == 0) ? 1 : 0;
   dfree(c->dAccum);
   dfree(c->dImage);
   LPT_HIP(c, hipSetDevice(c->device));
