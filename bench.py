@@ -36,12 +36,12 @@ class _DeviceArray:
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--spp-per-step", type=int, default=8, help="frames per step and per GPU")
+    ap.add_argument("--spp-per-step", type=int, default=32, help="frames per step and per GPU")
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_box.gltf"))
@@ -189,6 +189,8 @@ def main():
             "camera_paths": paths_total,
             "mean_path_length": seg_total / max(paths_total, 1.0),
             "device_ms_rank0": dev_ms,
+            "extend_ms_rank0": ext_ms,
+            "extend_launches_rank0": ext_launches,
             "gather_ms": gather_ms,
         }
         cpu = None

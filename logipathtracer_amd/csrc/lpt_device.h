@@ -15,18 +15,22 @@ constexpr uint32_t kRussianRouletteBounces = 2;
 
 // ---- traversal references -------------------------------------------------------
 // A reference is what the traversal stack holds (the reference shader's stack holds
-// node indices, path_tracing.comp:141,181).  Inner node: index into the derived
-// node array.  Leaf: bit 31 set, bits 24..30 = primitive count (<=127), bits 0..23 =
-// first primitive (mesh-relative triangle, or object index in the object tree).
+// node indices, path_tracing.comp:141,181).  Inner node: index into the derived node
+// array (object tree and all mesh trees share one array).  Leaf: bit 31 set, bits
+// 25..30 = primitive count (<=63), bits 0..24 = first primitive: an index into the
+// derived triangle array (mesh trees) or an object index (object tree).
 constexpr uint32_t kRefLeafBit = 0x80000000u;
 constexpr uint32_t kRefSentinel = 0xFFFFFFFFu;  // bottom of stack ("-1" in the shader)
 constexpr uint32_t kRefMarker = 0x7FFFFFFFu;    // end of an object's mesh tree
-constexpr uint32_t kMaxLeafCount = 127u;
-constexpr uint32_t kMaxLeafFirst = 0x00FFFFFEu;
+constexpr uint32_t kRefFirstMask = 0x01FFFFFFu;
+constexpr uint32_t kMaxLeafCount = 63u;
+constexpr uint32_t kMaxLeafFirst = 0x01FFFFFEu;
 
 __host__ __device__ inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) {
-  return kRefLeafBit | (count << 24) | first;
+  return kRefLeafBit | (count << 25) | first;
 }
+__host__ __device__ inline uint32_t leaf_first(uint32_t ref) { return ref & kRefFirstMask; }
+__host__ __device__ inline uint32_t leaf_count(uint32_t ref) { return (ref >> 25) & 0x3Fu; }
 
 // Derived inner node, 64 B: the boxes of BOTH children (the interchange node,
 // path_tracing.comp:29-39, stores its own box, so a visit there costs three node
@@ -39,9 +43,11 @@ struct alignas(16) TNode {
 };
 static_assert(sizeof(TNode) == 64, "TNode must be 64 bytes");
 
-// Triangle for intersection: corner 0 and the two edges of ray.glsl:64-65.
+// Triangle for intersection: corner 0 and the two edges of ray.glsl:64-65, plus the
+// index of its first vertex in the interchange vertex buffer (what a hit reports).
 struct alignas(16) Tri {
-  float v0[3], pad0;
+  float v0[3];
+  uint32_t prim;
   float e1[3], pad1;
   float e2[3], pad2;
 };
@@ -51,8 +57,7 @@ static_assert(sizeof(Tri) == 48, "Tri must be 48 bytes");
 struct alignas(16) ObjTrav {
   float inv[12];     // worldMatrixInverse rows 0..2: (m0 m4 m8 m12), (m1 ...), (m2 ...)
   uint32_t rootRef;  // reference of the mesh tree's root (never box-tested, path_tracing.comp:144)
-  uint32_t triBase;  // verticesOffset / 3
-  uint32_t pad[2];
+  uint32_t pad[3];
 };
 static_assert(sizeof(ObjTrav) == 64, "ObjTrav must be 64 bytes");
 
@@ -70,14 +75,16 @@ struct alignas(16) ObjShade {
 };
 static_assert(sizeof(ObjShade) == 128, "ObjShade must be 128 bytes");
 
+// Nodes and triangles are stored hottest first (largest world-space box first, parents
+// before children), so that a prefix of each array is what a kernel wants to keep in LDS.
 struct DScene {
-  const TNode* tlas;
-  const TNode* blas;
+  const TNode* nodes;
   const Tri* tris;
   const ObjTrav* otrav;
   const ObjShade* oshade;
   const lpt_vertex* verts;
-  uint32_t tlasRootRef;
+  uint32_t rootRef;   // reference of the object tree's root
+  uint32_t nNodes, nTris, nObjects;
 };
 
 struct Hit {
@@ -136,13 +143,12 @@ __device__ __forceinline__ Hit intersect_scene(const DScene& sc, f3 wo, f3 wd, u
   Hit hit{kInfinity, 0u, 0u};
   const f3 winv{1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z};
   f3 co = wo, cd = wd, cinv = winv;
-  const TNode* nodes = sc.tlas;
   bool inObj = false;
-  uint32_t curObj = 0, triBase = 0;
+  uint32_t curObj = 0;
   int sp = 0;
   stk[0] = kRefSentinel;
   sp = 1;
-  uint32_t cur = sc.tlasRootRef;
+  uint32_t cur = sc.rootRef;
 
   while (cur != kRefSentinel) {
     if (cur == kRefMarker) {  // finished an object's mesh tree: back to world space
@@ -150,12 +156,11 @@ __device__ __forceinline__ Hit intersect_scene(const DScene& sc, f3 wo, f3 wd, u
       co = wo;
       cd = wd;
       cinv = winv;
-      nodes = sc.tlas;
       cur = stk[(--sp) * stride];
       continue;
     }
     if (!(cur & kRefLeafBit)) {
-      const float4* q = reinterpret_cast<const float4*>(nodes + cur);
+      const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
       float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
       float c0mn[3] = {q0.x, q0.y, q0.z}, c0mx[3] = {q0.w, q1.x, q1.y};
       float c1mn[3] = {q1.z, q1.w, q2.x}, c1mx[3] = {q2.y, q2.z, q2.w};
@@ -172,17 +177,17 @@ __device__ __forceinline__ Hit intersect_scene(const DScene& sc, f3 wo, f3 wd, u
       }
       continue;
     }
-    uint32_t first = cur & 0x00FFFFFFu;
-    uint32_t count = (cur >> 24) & 0x7Fu;
+    uint32_t first = leaf_first(cur);
+    uint32_t count = leaf_count(cur);
     if (inObj) {
       for (uint32_t i = first; i < first + count; ++i) {
-        const float4* tq = reinterpret_cast<const float4*>(sc.tris + (triBase + i));
+        const float4* tq = reinterpret_cast<const float4*>(sc.tris + i);
         float4 a = tq[0], b = tq[1], c = tq[2];
         float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
         if (td > kEps && td < hit.t) {
           hit.t = td;
           hit.obj = curObj;
-          hit.prim = 3u * (triBase + i);
+          hit.prim = as_uint(a.w);
         }
       }
       cur = stk[(--sp) * stride];
@@ -200,8 +205,6 @@ __device__ __forceinline__ Hit intersect_scene(const DScene& sc, f3 wo, f3 wd, u
       cd = xform_dir(rows, wd);
       cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
       curObj = first;
-      triBase = as_uint(r3.y);
-      nodes = sc.blas;
       inObj = true;
       cur = as_uint(r3.x);
     }

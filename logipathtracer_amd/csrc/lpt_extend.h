@@ -18,55 +18,63 @@
 
 namespace lpt {
 
-constexpr uint32_t kFetchChunk = 512;  // rays per cursor atomic
+// Rays are handed out in chunks of kFetchChunk.  The queue is cut into kCursorRegions equal
+// regions with one cursor each (a single atomic word would serialise all waves); a wave
+// starts in the region of its workgroup and moves on to the next one when it runs dry.
+constexpr uint32_t kFetchChunk = 128;
+constexpr uint32_t kCursorRegions = 8;
+#ifndef LPT_FETCH_THRESHOLD
+#define LPT_FETCH_THRESHOLD 16
+#endif
 constexpr int kStFetch = 0, kStInner = 1, kStTri = 2, kStObj = 3, kStDone = 4;
 
-template <int S, int BLOCK>
+// LDS image of one block: the traversal stacks plus the hottest prefix of the scene arrays
+// (they are stored hottest first).  KN nodes, KT triangles, KO object records.
+template <int S, int BLOCK, int KN, int KT, int KO>
+struct ExtendShared {
+  uint32_t stack[S * BLOCK];
+  float4 nodes[KN > 0 ? KN * 4 : 1];
+  float4 tris[KT > 0 ? KT * 3 : 1];
+  float4 objs[KO > 0 ? KO * 4 : 1];
+};
+
+template <int S, int BLOCK, int KN, int KT, int KO>
 __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4* __restrict__ qo,
                                                   const float4* __restrict__ qd, uint32_t n,
-                                                  float4* __restrict__ hits, uint32_t* cursor, uint32_t* stack) {
-  uint32_t* stk = &stack[threadIdx.x];
+                                                  float4* __restrict__ hits, uint32_t* cursor,
+                                                  ExtendShared<S, BLOCK, KN, KT, KO>& sh) {
+  uint32_t* stk = &sh.stack[threadIdx.x];
   const uint32_t lane = threadIdx.x & 63u;
+
+  // fill the LDS copies of the hot prefixes
+  const uint32_t hotNodes = min((uint32_t)KN, sc.nNodes);
+  const uint32_t hotTris = min((uint32_t)KT, sc.nTris);
+  const uint32_t hotObjs = min((uint32_t)KO, sc.nObjects);
+  if (KN > 0 || KT > 0 || KO > 0) {
+    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* gt = reinterpret_cast<const float4*>(sc.tris);
+    const float4* go = reinterpret_cast<const float4*>(sc.otrav);
+    for (uint32_t i = threadIdx.x; i < hotNodes * 4u; i += BLOCK) sh.nodes[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < hotTris * 3u; i += BLOCK) sh.tris[i] = gt[i];
+    for (uint32_t i = threadIdx.x; i < hotObjs * 4u; i += BLOCK) sh.objs[i] = go[i];
+    __syncthreads();
+  }
 
   // wave-uniform chunk of ray indices [chunkNext, chunkEnd)
   uint32_t chunkNext = 0, chunkEnd = 0;
   bool exhausted = false;
+  const uint32_t regionSize = (n + kCursorRegions - 1u) / kCursorRegions;
+  uint32_t region = blockIdx.x % kCursorRegions;  // region being drained
+  uint32_t regionsTried = 0;
 
   int state = kStFetch;
   f3 wo{0, 0, 0}, wd{0, 0, 0}, winv{0, 0, 0};  // ray in world space
   f3 co{0, 0, 0}, cd{0, 0, 0}, cinv{0, 0, 0};  // ray in the space being traversed
   Hit hit{kInfinity, 0u, 0u};
   bool inObj = false;
-  uint32_t curObj = 0, triBase = 0, triI = 0, triEnd = 0;
+  uint32_t curObj = 0, triI = 0, triEnd = 0;
   uint32_t cur = kRefSentinel, rayIdx = 0;
   int sp = 0;
-
-  // Pops the next reference; leaving an object's mesh tree restores the world-space ray.
-  auto pop = [&]() {
-    cur = stk[(--sp) * BLOCK];
-    if (cur == kRefMarker) {
-      inObj = false;
-      co = wo;
-      cd = wd;
-      cinv = winv;
-      cur = stk[(--sp) * BLOCK];
-    }
-  };
-  // Decides what the lane needs next from the reference it now holds.
-  auto dispatch = [&]() {
-    if (cur == kRefSentinel) {
-      hits[rayIdx] = make_float4(hit.t, as_float(hit.obj), as_float(hit.prim), 0.0f);
-      state = kStFetch;
-    } else if (!(cur & kRefLeafBit)) {
-      state = kStInner;
-    } else if (inObj) {
-      triI = cur & 0x00FFFFFFu;
-      triEnd = triI + ((cur >> 24) & 0x7Fu);
-      state = kStTri;
-    } else {
-      state = kStObj;
-    }
-  };
 
   for (;;) {
     const unsigned long long bF = __ballot(state == kStFetch);
@@ -77,17 +85,22 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     const int busy = nI + nT + nO;
     if (busy + nF == 0) break;
 
+    bool stepped = false;  // this lane advanced and holds a new `cur` (or needs a pop)
+    bool needPop = false;
+
     // Idle lanes are pure loss, so refill as soon as a fair number waits (or nothing else is left).
-    if (nF > 0 && (nF >= 16 || busy == 0)) {
-      if (!exhausted && chunkNext >= chunkEnd) {
+    if (nF > 0 && (nF >= LPT_FETCH_THRESHOLD || busy == 0)) {
+      while (!exhausted && chunkNext >= chunkEnd) {
+        const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
         uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(cursor, kFetchChunk);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
-        if (b >= n) {
-          exhausted = true;
-        } else {
+        if (lane == 0) b = atomicAdd(&cursor[region], kFetchChunk);
+        b = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
+        if (lo < hi && b < hi) {
           chunkNext = b;
-          chunkEnd = min(b + kFetchChunk, n);
+          chunkEnd = min(b + kFetchChunk, hi);
+        } else {
+          region = (region + 1u) % kCursorRegions;
+          if (++regionsTried >= kCursorRegions) exhausted = true;
         }
       }
       if (exhausted) {
@@ -110,74 +123,109 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
             inObj = false;
             stk[0] = kRefSentinel;
             sp = 1;
-            cur = sc.tlasRootRef;
-            dispatch();
+            cur = sc.rootRef;
+            stepped = true;
           }
         }
         chunkNext += min((uint32_t)nF, avail);
       }
-      continue;
-    }
-
-    if (nI >= nT && nI >= nO) {
+    } else if (nI >= nT && nI >= nO) {
       if (state == kStInner) {
-        const TNode* nodes = inObj ? sc.blas : sc.tlas;
-        const float4* q = reinterpret_cast<const float4*>(nodes + cur);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        float4 q0, q1, q2, q3;
+        if (cur < hotNodes) {
+          const float4* q = &sh.nodes[cur * 4u];
+          q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+        } else {
+          const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+          q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+        }
         const float c0mn[3] = {q0.x, q0.y, q0.z}, c0mx[3] = {q0.w, q1.x, q1.y};
         const float c1mn[3] = {q1.z, q1.w, q2.x}, c1mx[3] = {q2.y, q2.z, q2.w};
         const bool h0 = box_test(co, cinv, c0mn, c0mx, hit.t);
         const bool h1 = box_test(co, cinv, c1mn, c1mx, hit.t);
         const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-        if (h1) {
-          if (h0) stk[(sp++) * BLOCK] = r0;
-          cur = r1;
-        } else if (h0) {
-          cur = r0;
-        } else {
-          pop();
-        }
-        dispatch();
+        if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+        cur = h1 ? r1 : r0;
+        needPop = !(h0 || h1);
+        stepped = true;
       }
     } else if (nT >= nO) {
       if (state == kStTri) {
         if (triI < triEnd) {
-          const float4* tq = reinterpret_cast<const float4*>(sc.tris + (triBase + triI));
-          const float4 a = tq[0], b = tq[1], c = tq[2];
+          float4 a, b, c;
+          if (triI < hotTris) {
+            const float4* tq = &sh.tris[triI * 3u];
+            a = tq[0]; b = tq[1]; c = tq[2];
+          } else {
+            const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
+            a = tq[0]; b = tq[1]; c = tq[2];
+          }
           const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
           if (td > kEps && td < hit.t) {
             hit.t = td;
             hit.obj = curObj;
-            hit.prim = 3u * (triBase + triI);
+            hit.prim = as_uint(a.w);
           }
           ++triI;
         }
         if (triI >= triEnd) {
-          pop();
-          dispatch();
+          needPop = true;
+          stepped = true;
         }
       }
     } else {
       if (state == kStObj) {
-        const uint32_t first = cur & 0x00FFFFFFu;
-        const uint32_t count = (cur >> 24) & 0x7Fu;
+        const uint32_t first = leaf_first(cur);
+        const uint32_t count = leaf_count(cur);
         if (count == 0u) {
-          pop();
+          needPop = true;
         } else {
           if (count > 1u) stk[(sp++) * BLOCK] = make_leaf_ref(first + 1u, count - 1u);
           stk[(sp++) * BLOCK] = kRefMarker;
-          const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
-          const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
+          float4 r0, r1, r2, r3;
+          if (first < hotObjs) {
+            const float4* oq = &sh.objs[first * 4u];
+            r0 = oq[0]; r1 = oq[1]; r2 = oq[2]; r3 = oq[3];
+          } else {
+            const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
+            r0 = oq[0]; r1 = oq[1]; r2 = oq[2]; r3 = oq[3];
+          }
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
           co = xform_point(rows, wo);
           cd = xform_dir(rows, wd);
           cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
           curObj = first;
-          triBase = as_uint(r3.y);
           inObj = true;
           cur = as_uint(r3.x);
         }
-        dispatch();
+        stepped = true;
+      }
+    }
+
+    // Common tail: take the next reference off the stack if needed and decide what the
+    // lane waits for next.  Leaving an object's mesh tree restores the world-space ray.
+    if (stepped) {
+      if (needPop) {
+        cur = stk[(--sp) * BLOCK];
+        if (cur == kRefMarker) {
+          inObj = false;
+          co = wo;
+          cd = wd;
+          cinv = winv;
+          cur = stk[(--sp) * BLOCK];
+        }
+      }
+      if (cur == kRefSentinel) {
+        hits[rayIdx] = make_float4(hit.t, as_float(hit.obj), as_float(hit.prim), 0.0f);
+        state = kStFetch;
+      } else if (!(cur & kRefLeafBit)) {
+        state = kStInner;
+      } else if (inObj) {
+        triI = leaf_first(cur);
+        triEnd = triI + leaf_count(cur);
+        state = kStTri;
+      } else {
+        state = kStObj;
       }
     }
   }

@@ -14,7 +14,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <new>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -101,14 +103,15 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
   }
 }
 
-// Closest hit for every queued ray: persistent waves, node stack in LDS (one column per
-// thread), rays handed out through `cursor` (zeroed before the launch).  See lpt_extend.h.
-template <int S>
-__global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
-                                                   const float4* __restrict__ qd, const uint32_t* __restrict__ count,
-                                                   float4* __restrict__ hits, uint32_t* cursor) {
-  __shared__ uint32_t stack[S * kBlock];
-  extend_persistent<S, kBlock>(sc, qo, qd, *count, hits, cursor, stack);
+// Closest hit for every queued ray: persistent waves, node stacks and the hottest part of
+// the scene in LDS, rays handed out through `cursor` (zeroed before the launch).  See
+// lpt_extend.h.  BLOCK threads per workgroup, one workgroup per CU when the caches are used.
+template <int S, int BLOCK, int KN, int KT, int KO>
+__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, const float4* __restrict__ qo,
+                                                  const float4* __restrict__ qd, const uint32_t* __restrict__ count,
+                                                  float4* __restrict__ hits, uint32_t* cursor) {
+  __shared__ ExtendShared<S, BLOCK, KN, KT, KO> sh;
+  extend_persistent<S, BLOCK, KN, KT, KO>(sc, qo, qd, *count, hits, cursor, sh);
 }
 
 // Shades every queued hit, samples the next direction, applies Russian roulette; paths
@@ -314,13 +317,13 @@ struct lpt_ctx {
   std::string err;
 
   // scene (device)
-  TNode* dTlas = nullptr;
-  TNode* dBlas = nullptr;
+  TNode* dNodes = nullptr;  // object tree + mesh trees, hottest first
   Tri* dTris = nullptr;
   ObjTrav* dObjTrav = nullptr;
   ObjShade* dObjShade = nullptr;
   lpt_vertex* dVerts = nullptr;
-  uint32_t tlasRootRef = kRefSentinel;
+  uint32_t rootRef = kRefSentinel;
+  uint32_t nNodes = 0, nTris = 0, nObjects = 0;
   int stackNeed = 0;
   bool sceneLoaded = false;
 
@@ -335,7 +338,7 @@ struct lpt_ctx {
   int bsdfMode = LPT_BSDF_HEITZ;
   int pipeline = LPT_PIPELINE_WAVEFRONT;
   int framesInFlight = 0;
-  int extendBlocksPerCU = 6;
+  int extendBlocksPerCU = 8;
 
   // wavefront pool
   size_t poolPaths = 0;
@@ -344,7 +347,7 @@ struct lpt_ctx {
   Queue queues[2]{};
   float4* dHits = nullptr;
   float4* dSamples = nullptr;
-  uint32_t* dCounts = nullptr;   // [poolBounces] queue fills, then [poolBounces] ray cursors of k_extend
+  uint32_t* dCounts = nullptr;   // [poolBounces] queue fills, then [poolBounces][kCursorRegions] ray cursors of k_extend
   lpt_ubo* dUbos = nullptr;
   lpt_ubo* hUbos = nullptr;  // pinned staging
   int ubosCap = 0;
@@ -379,8 +382,7 @@ void dfree(T*& p) {
 }
 
 void free_scene(lpt_ctx* c) {
-  dfree(c->dTlas);
-  dfree(c->dBlas);
+  dfree(c->dNodes);
   dfree(c->dTris);
   dfree(c->dObjTrav);
   dfree(c->dObjShade);
@@ -396,48 +398,42 @@ void free_pool(lpt_ctx* c) {
 }
 
 DScene device_scene(const lpt_ctx* c) {
-  return DScene{c->dTlas, c->dBlas, c->dTris, c->dObjTrav, c->dObjShade, c->dVerts, c->tlasRootRef};
+  return DScene{c->dNodes, c->dTris, c->dObjTrav, c->dObjShade, c->dVerts, c->rootRef, c->nNodes, c->nTris, c->nObjects};
 }
 
-// Builds derived inner nodes for the tree rooted at `root` (indices in `nodes` are
-// offset by `base`) and returns the number of stack entries a traversal of it can hold
-// at once, excluding what leaves of the object tree add.  leafNeed(first,count) gives
-// the extra need of a leaf.  Iterative post-order; rejects cycles and bad indices.
+// Validates the binary tree rooted at nodes[base] (child indices are offset by `base`) and
+// returns the number of stack entries a traversal of it can hold at once; leafNeed(first,count)
+// gives what a leaf adds (and validates its range; negative = error code).  Iterative
+// post-order; rejects bad indices, cycles and leaves too large for a traversal reference.
 template <typename LeafNeed>
-int derive_tree(const lpt_bvh_node* nodes, uint32_t nNodes, uint32_t base, std::vector<TNode>& out,
-                std::vector<int>& need, uint32_t* rootRef, LeafNeed leafNeed, std::string& err) {
+int tree_need(const lpt_bvh_node* nodes, uint32_t nNodes, uint32_t base, std::vector<int>& need, LeafNeed leafNeed,
+              std::string& err) {
   if (base >= nNodes) {
     err = "BVH root index out of range";
     return LPT_ERR_INVALID;
   }
-  auto leaf_ref = [&](const lpt_bvh_node& n, uint32_t* ref) -> int {
+  auto leaf = [&](const lpt_bvh_node& n) -> int {
     uint32_t first = n.indices[0], last = n.indices[1];
     uint32_t count = last > first ? last - first : 0u;
-    if (count > kMaxLeafCount || first > kMaxLeafFirst) {
-      err = "BVH leaf range cannot be encoded (more than 127 primitives or first >= 2^24-1)";
+    if (count > kMaxLeafCount) {
+      err = "BVH leaf holds more than 63 primitives";
       return LPT_ERR_UNSUPPORTED;
     }
-    *ref = make_leaf_ref(first, count);
-    return 0;
+    return leafNeed(first, count);
   };
-  const lpt_bvh_node& r = nodes[base];
-  if (r.isLeaf) {
-    int rc = leaf_ref(r, rootRef);
-    if (rc) return rc;
-    return leafNeed(r.indices[0], r.indices[1] > r.indices[0] ? r.indices[1] - r.indices[0] : 0u);
-  }
-  *rootRef = base;
-  // need[] doubles as the visit state: -2 unvisited, -1 on stack, >=0 done
+  if (nodes[base].isLeaf) return leaf(nodes[base]);
+  // need[] doubles as the visit state: -2 unvisited, -1 on the stack, >=0 done
   std::vector<uint32_t> st;
   st.push_back(base);
   while (!st.empty()) {
     uint32_t i = st.back();
     const lpt_bvh_node& n = nodes[i];
-    uint32_t c[2] = {base + n.indices[0], base + n.indices[1]};
-    if (c[0] >= nNodes || c[1] >= nNodes) {
+    uint64_t c64[2] = {(uint64_t)base + n.indices[0], (uint64_t)base + n.indices[1]};
+    if (c64[0] >= nNodes || c64[1] >= nNodes) {
       err = "BVH child index out of range";
       return LPT_ERR_INVALID;
     }
+    uint32_t c[2] = {(uint32_t)c64[0], (uint32_t)c64[1]};
     if (need[i] == -2) {
       need[i] = -1;
       bool pushed = false;
@@ -455,34 +451,38 @@ int derive_tree(const lpt_bvh_node* nodes, uint32_t nNodes, uint32_t base, std::
       }
       if (pushed) continue;
     }
-    // children done: emit the derived node
-    TNode t{};
     int cn[2];
-    uint32_t refs[2];
     for (int k = 0; k < 2; ++k) {
-      const lpt_bvh_node& ch = nodes[c[k]];
-      if (ch.isLeaf) {
-        int rc = leaf_ref(ch, &refs[k]);
-        if (rc) return rc;
-        cn[k] = leafNeed(ch.indices[0], ch.indices[1] > ch.indices[0] ? ch.indices[1] - ch.indices[0] : 0u);
+      if (nodes[c[k]].isLeaf) {
+        cn[k] = leaf(nodes[c[k]]);
         if (cn[k] < 0) return cn[k];
       } else {
-        refs[k] = c[k];
         cn[k] = need[c[k]];
       }
     }
-    std::memcpy(t.c0min, nodes[c[0]].minCorner, 12);
-    std::memcpy(t.c0max, nodes[c[0]].maxCorner, 12);
-    std::memcpy(t.c1min, nodes[c[1]].minCorner, 12);
-    std::memcpy(t.c1max, nodes[c[1]].maxCorner, 12);
-    t.ref0 = refs[0];
-    t.ref1 = refs[1];
-    out[i] = t;
     // child 1 is walked first while child 0 may wait on the stack
     need[i] = std::max(1 + cn[1], cn[0]);
     st.pop_back();
   }
   return need[base];
+}
+
+// Surface area of the world-space box of an object-space box.
+float world_area(const float* mn, const float* mx, const float* m /* column-major 4x4, or null */) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = 0; k < 8; ++k) {
+    float p[3] = {(k & 1) ? mx[0] : mn[0], (k & 2) ? mx[1] : mn[1], (k & 4) ? mx[2] : mn[2]};
+    float q[3] = {p[0], p[1], p[2]};
+    if (m)
+      for (int r = 0; r < 3; ++r) q[r] = m[r] * p[0] + m[4 + r] * p[1] + m[8 + r] * p[2] + m[12 + r];
+    for (int r = 0; r < 3; ++r) {
+      lo[r] = std::min(lo[r], q[r]);
+      hi[r] = std::max(hi[r], q[r]);
+    }
+  }
+  float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+  if (!(d[0] >= 0.0f && d[1] >= 0.0f && d[2] >= 0.0f)) return 0.0f;
+  return 2.0f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
 }
 
 int ensure_events(lpt_ctx* c, size_t n) {
@@ -496,9 +496,12 @@ int ensure_events(lpt_ctx* c, size_t n) {
 
 int auto_frames_in_flight(const lpt_ctx* c) {
   if (c->framesInFlight > 0) return c->framesInFlight;
-  const double target = 8.0 * 1024 * 1024;  // paths in flight
+  // Every traversal launch ends with a latency-bound tail (its longest rays), whatever the
+  // number of rays, so large batches pay off: aim for 64 Mi paths in flight (about 10 GiB of
+  // queues at 160 B per path).
+  const double target = 64.0 * 1024 * 1024;
   int f = (int)(target / std::max<uint32_t>(c->part.nSlots, 1u));
-  return std::min(64, std::max(1, f));
+  return std::min(256, std::max(1, f));
 }
 
 int ensure_pool(lpt_ctx* c, int frames) {
@@ -521,7 +524,7 @@ int ensure_pool(lpt_ctx* c, int frames) {
   }
   if (c->maxBounces + 1 > c->poolBounces) {
     dfree(c->dCounts);
-    LPT_HIP(c, hipMalloc(&c->dCounts, 2 * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
+    LPT_HIP(c, hipMalloc(&c->dCounts, (1 + kCursorRegions) * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
     c->poolBounces = c->maxBounces + 1;
   }
   if (frames > c->ubosCap) {
@@ -541,19 +544,26 @@ int grid_for(const lpt_ctx* c, size_t items, int blocksPerCU) {
   return (int)std::max<size_t>(1, std::min(need, cap));
 }
 
-template <int S>
+template <int S, int BLOCK, int KN, int KT, int KO>
 int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
-  // persistent grid: LDS bounds residency (S KiB per block of 256 threads, 160 KiB per CU)
-  int perCU = std::max(1, std::min(c->extendBlocksPerCU, 160 / S));
-  hipLaunchKernelGGL(k_extend<S>, dim3(grid_for(c, maxItems, perCU)), dim3(kBlock), 0, c->stream, device_scene(c), q.o,
+  // persistent grid sized by LDS residency (160 KiB per CU)
+  const size_t ldsBytes = sizeof(ExtendShared<S, BLOCK, KN, KT, KO>);
+  int perCU = std::max<int>(1, std::min<int>(2048 / BLOCK, (int)(160 * 1024 / ldsBytes)));
+  size_t need = (maxItems + BLOCK - 1) / BLOCK;
+  int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
+  hipLaunchKernelGGL((k_extend<S, BLOCK, KN, KT, KO>), dim3(grid), dim3(BLOCK), 0, c->stream, device_scene(c), q.o,
                      q.d, count, c->dHits, cursor);
   return 0;
 }
 
 int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
-  if (c->stackNeed <= 16) return launch_extend<16>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 32) return launch_extend<32>(c, q, count, cursor, maxItems);
-  return launch_extend<64>(c, q, count, cursor, maxItems);
+  // One 1024-thread workgroup per CU: S KiB * 4 of stacks, the rest of the 160 KiB LDS holds the
+  // hottest nodes (64 B), triangles (48 B) and object records (64 B).
+  if (c->stackNeed <= 20) return launch_extend<20, 1024, 768, 512, 32>(c, q, count, cursor, maxItems);   // 80+48+24+2 KiB
+  if (c->stackNeed <= 24) return launch_extend<24, 1024, 576, 448, 32>(c, q, count, cursor, maxItems);   // 96+36+21+2
+  if (c->stackNeed <= 32) return launch_extend<32, 1024, 288, 224, 32>(c, q, count, cursor, maxItems);   // 128+18+10.5+2
+  if (c->stackNeed <= 48) return launch_extend<48, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
+  return launch_extend<64, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
 }
 
 int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
@@ -563,7 +573,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   const uint32_t nB = (uint32_t)c->maxBounces;
   std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
   LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, 2 * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorRegions) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   uint32_t* cursors = c->dCounts + c->poolBounces;
   const int dense = c->part.dense ? 1 : 0;
   if (dense) {
@@ -579,7 +589,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-    dispatch_extend(c, in, c->dCounts + b, cursors + b, paths);
+    dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
                        c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
@@ -735,57 +745,27 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
   LPT_HIP(c, hipStreamSynchronize(c->stream));
 
   std::string err;
-  // mesh trees, one per object
-  std::vector<TNode> blas(nMeshBvh);
+  const uint32_t nTrisIn = nVerts / 3u;
+
+  // 1. validate both levels and size the traversal stack
   std::vector<int> needB(nMeshBvh, -2);
-  std::vector<ObjTrav> otrav(nObj);
-  std::vector<ObjShade> oshade(nObj);
-  std::vector<float> baseColor(4 * (size_t)nObj);
   std::vector<int> objNeed(nObj, 0);
-  const uint32_t nTris = nVerts / 3u;
   for (uint32_t i = 0; i < nObj; ++i) {
-    const lpt_object& o = objects[i];
-    uint32_t triBase = o.verticesOffset / 3u;
-    uint32_t rootRef = 0;
+    const uint32_t triBase = objects[i].verticesOffset / 3u;
     auto triLeaf = [&](uint32_t first, uint32_t count) -> int {
-      if ((size_t)triBase + first + count > nTris) {
+      if ((uint64_t)triBase + first + count > nTrisIn) {
         err = "mesh BVH leaf references triangles outside the vertex buffer";
         return LPT_ERR_INVALID;
       }
       return 0;
     };
-    int need = derive_tree(meshBvh, nMeshBvh, o.bvhOffset, blas, needB, &rootRef, triLeaf, err);
+    int need = tree_need(meshBvh, nMeshBvh, objects[i].bvhOffset, needB, triLeaf, err);
     if (need < 0) return fail(c, need, err);
     objNeed[i] = need;
-    ObjTrav& t = otrav[i];
-    ObjShade& s = oshade[i];
-    const float* mi = o.worldMatrixInverse;
-    const float* mw = o.worldMatrix;
-    for (int r = 0; r < 3; ++r) {
-      for (int k = 0; k < 4; ++k) t.inv[4 * r + k] = s.inv[4 * r + k] = mi[4 * k + r];
-      for (int k = 0; k < 3; ++k) s.nrm[3 * r + k] = mw[4 * k + r];
-    }
-    t.rootRef = rootRef;
-    t.triBase = triBase;
-    t.pad[0] = t.pad[1] = 0;
-    for (int k = 0; k < 3; ++k) {
-      s.baseLinear[k] = 0.0f;
-      s.emission[k] = o.emissionFactor[k];
-    }
-    float rf = o.roughnessFactor;
-    s.roughness = (rf != rf) ? 0.001f : (rf < 0.001f ? 0.001f : rf);  // max(roughness, 0.001)
-    s.metallic = o.metallicFactor;
-    s.transmission = o.transmissionFactor;
-    s.ior = o.ior;
-    s.pad = 0.0f;
-    std::memcpy(&baseColor[4 * (size_t)i], o.baseColorFactor, 16);
   }
-  // object tree
-  std::vector<TNode> tlas(nObjBvh);
   std::vector<int> needT(nObjBvh, -2);
-  uint32_t tlasRoot = 0;
   auto objLeaf = [&](uint32_t first, uint32_t count) -> int {
-    if ((size_t)first + count > nObj) {
+    if ((uint64_t)first + count > nObj) {
       err = "object BVH leaf references objects outside the object buffer";
       return LPT_ERR_INVALID;
     }
@@ -793,34 +773,158 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
     for (uint32_t k = first; k < first + count; ++k) worst = std::max(worst, objNeed[k]);
     return (count > 1u ? 2 : 1) + worst;  // remaining-range entry + end-of-object marker
   };
-  int needScene = derive_tree(objBvh, nObjBvh, 0, tlas, needT, &tlasRoot, objLeaf, err);
+  int needScene = tree_need(objBvh, nObjBvh, 0, needT, objLeaf, err);
   if (needScene < 0) return fail(c, needScene, err);
   int stackNeed = needScene + 1;  // bottom-of-stack sentinel
   if (stackNeed > 64) return fail(c, LPT_ERR_STACK, "BVH needs a traversal stack deeper than 64 entries");
 
-  std::vector<Tri> tris(nTris);
-  for (uint32_t t = 0; t < nTris; ++t) {
-    const lpt_vertex* v = verts + 3 * (size_t)t;
-    Tri& tr = tris[t];
-    for (int k = 0; k < 3; ++k) {
-      tr.v0[k] = v[0].position[k];
-      tr.e1[k] = v[1].position[k] - v[0].position[k];
-      tr.e2[k] = v[2].position[k] - v[0].position[k];
+  // 2. order nodes and leaf triangles hottest first: best-first expansion from the scene
+  //    root by world-space surface area (the chance that a random ray meets the box)
+  struct Item {
+    float prio;
+    uint32_t seq;   // insertion order breaks ties deterministically
+    int kind;       // 0 object-tree inner node, 1 mesh-tree inner node, 2 mesh-tree leaf
+    uint32_t node;  // index into objBvh (kind 0) or meshBvh (kinds 1, 2)
+    uint32_t obj;
+    bool operator<(const Item& o) const { return prio != o.prio ? prio < o.prio : seq > o.seq; }
+  };
+  std::priority_queue<Item> heap;
+  uint32_t seq = 0;
+  std::vector<int64_t> newT(nObjBvh, -1), newB(nMeshBvh, -1), newTri(nMeshBvh, -1);
+  struct Placed { int kind; uint32_t node; uint32_t obj; };
+  std::vector<Placed> order;
+  std::vector<Tri> tris;
+  auto enterObject = [&](uint32_t oi, float prio) {
+    uint32_t root = objects[oi].bvhOffset;
+    heap.push(Item{prio, seq++, meshBvh[root].isLeaf ? 2 : 1, root, oi});
+  };
+  auto expandObjLeaf = [&](const lpt_bvh_node& n) {
+    float prio = world_area(n.minCorner, n.maxCorner, nullptr);
+    uint32_t first = n.indices[0], last = std::max(n.indices[0], n.indices[1]);
+    for (uint32_t k = first; k < last; ++k) enterObject(k, prio);
+  };
+  if (objBvh[0].isLeaf) expandObjLeaf(objBvh[0]);
+  else heap.push(Item{INFINITY, seq++, 0, 0u, 0u});
+  while (!heap.empty()) {
+    Item it = heap.top();
+    heap.pop();
+    if (it.kind == 0) {
+      if (newT[it.node] >= 0) continue;
+      newT[it.node] = (int64_t)order.size();
+      order.push_back(Placed{0, it.node, 0u});
+      for (int k = 0; k < 2; ++k) {
+        uint32_t ci = objBvh[it.node].indices[k];
+        const lpt_bvh_node& ch = objBvh[ci];
+        if (ch.isLeaf) expandObjLeaf(ch);
+        else heap.push(Item{world_area(ch.minCorner, ch.maxCorner, nullptr), seq++, 0, ci, 0u});
+      }
+    } else if (it.kind == 1) {
+      if (newB[it.node] >= 0) continue;
+      newB[it.node] = (int64_t)order.size();
+      order.push_back(Placed{1, it.node, it.obj});
+      const uint32_t base = objects[it.obj].bvhOffset;
+      for (int k = 0; k < 2; ++k) {
+        uint32_t ci = base + meshBvh[it.node].indices[k];
+        const lpt_bvh_node& ch = meshBvh[ci];
+        heap.push(Item{world_area(ch.minCorner, ch.maxCorner, objects[it.obj].worldMatrix), seq++, ch.isLeaf ? 2 : 1, ci, it.obj});
+      }
+    } else {
+      if (newTri[it.node] >= 0) continue;
+      newTri[it.node] = (int64_t)tris.size();
+      const lpt_bvh_node& lf = meshBvh[it.node];
+      const uint32_t triBase = objects[it.obj].verticesOffset / 3u;
+      for (uint32_t t = lf.indices[0]; t < std::max(lf.indices[0], lf.indices[1]); ++t) {
+        const lpt_vertex* v = verts + 3 * (size_t)(triBase + t);
+        Tri tr;
+        for (int k = 0; k < 3; ++k) {
+          tr.v0[k] = v[0].position[k];
+          tr.e1[k] = v[1].position[k] - v[0].position[k];
+          tr.e2[k] = v[2].position[k] - v[0].position[k];
+        }
+        tr.prim = 3u * (triBase + t);
+        tr.pad1 = tr.pad2 = 0.0f;
+        tris.push_back(tr);
+      }
     }
-    tr.pad0 = tr.pad1 = tr.pad2 = 0.0f;
+  }
+  if (tris.size() > kMaxLeafFirst || order.size() >= kRefMarker)
+    return fail(c, LPT_ERR_UNSUPPORTED, "scene too large for 25-bit triangle references");
+
+  // 3. emit derived nodes and object records with references into the new order
+  auto meshLeafRef = [&](uint32_t leafIdx) {
+    const lpt_bvh_node& lf = meshBvh[leafIdx];
+    uint32_t count = lf.indices[1] > lf.indices[0] ? lf.indices[1] - lf.indices[0] : 0u;
+    return make_leaf_ref((uint32_t)newTri[leafIdx], count);
+  };
+  auto objLeafRef = [&](const lpt_bvh_node& lf) {
+    uint32_t count = lf.indices[1] > lf.indices[0] ? lf.indices[1] - lf.indices[0] : 0u;
+    return make_leaf_ref(lf.indices[0], count);
+  };
+  std::vector<TNode> nodes(std::max<size_t>(1, order.size()));
+  std::memset(nodes.data(), 0, nodes.size() * sizeof(TNode));
+  for (size_t i = 0; i < order.size(); ++i) {
+    const Placed& pl = order[i];
+    TNode t{};
+    const lpt_bvh_node* src = pl.kind == 0 ? objBvh : meshBvh;
+    const uint32_t base = pl.kind == 0 ? 0u : objects[pl.obj].bvhOffset;
+    uint32_t refs[2];
+    const lpt_bvh_node* ch[2];
+    for (int k = 0; k < 2; ++k) {
+      uint32_t ci = base + src[pl.node].indices[k];
+      ch[k] = &src[ci];
+      if (pl.kind == 0) refs[k] = ch[k]->isLeaf ? objLeafRef(*ch[k]) : (uint32_t)newT[ci];
+      else refs[k] = ch[k]->isLeaf ? meshLeafRef(ci) : (uint32_t)newB[ci];
+    }
+    std::memcpy(t.c0min, ch[0]->minCorner, 12);
+    std::memcpy(t.c0max, ch[0]->maxCorner, 12);
+    std::memcpy(t.c1min, ch[1]->minCorner, 12);
+    std::memcpy(t.c1max, ch[1]->maxCorner, 12);
+    t.ref0 = refs[0];
+    t.ref1 = refs[1];
+    nodes[i] = t;
+  }
+  const uint32_t sceneRoot = objBvh[0].isLeaf ? objLeafRef(objBvh[0]) : (uint32_t)newT[0];
+
+  std::vector<ObjTrav> otrav(nObj);
+  std::vector<ObjShade> oshade(nObj);
+  std::vector<float> baseColor(4 * (size_t)nObj);
+  for (uint32_t i = 0; i < nObj; ++i) {
+    const lpt_object& o = objects[i];
+    ObjTrav& t = otrav[i];
+    ObjShade& sh = oshade[i];
+    std::memset(&t, 0, sizeof t);
+    std::memset(&sh, 0, sizeof sh);
+    const float* mi = o.worldMatrixInverse;
+    const float* mw = o.worldMatrix;
+    for (int r = 0; r < 3; ++r) {
+      for (int k = 0; k < 4; ++k) t.inv[4 * r + k] = sh.inv[4 * r + k] = mi[4 * k + r];
+      for (int k = 0; k < 3; ++k) sh.nrm[3 * r + k] = mw[4 * k + r];
+    }
+    // an object never reached from the object tree keeps an empty root
+    t.rootRef = make_leaf_ref(0u, 0u);
+    if (meshBvh[o.bvhOffset].isLeaf) {
+      if (newTri[o.bvhOffset] >= 0) t.rootRef = meshLeafRef(o.bvhOffset);
+    } else if (newB[o.bvhOffset] >= 0) {
+      t.rootRef = (uint32_t)newB[o.bvhOffset];
+    }
+    for (int k = 0; k < 3; ++k) sh.emission[k] = o.emissionFactor[k];
+    float rf = o.roughnessFactor;
+    sh.roughness = (rf != rf) ? 0.001f : (rf < 0.001f ? 0.001f : rf);  // max(roughness, 0.001)
+    sh.metallic = o.metallicFactor;
+    sh.transmission = o.transmissionFactor;
+    sh.ior = o.ior;
+    std::memcpy(&baseColor[4 * (size_t)i], o.baseColorFactor, 16);
   }
 
   free_scene(c);
   float* dBase = nullptr;
-  LPT_HIP(c, hipMalloc(&c->dTlas, tlas.size() * sizeof(TNode)));
-  LPT_HIP(c, hipMalloc(&c->dBlas, blas.size() * sizeof(TNode)));
+  LPT_HIP(c, hipMalloc(&c->dNodes, nodes.size() * sizeof(TNode)));
   LPT_HIP(c, hipMalloc(&c->dTris, std::max<size_t>(1, tris.size()) * sizeof(Tri)));
   LPT_HIP(c, hipMalloc(&c->dObjTrav, otrav.size() * sizeof(ObjTrav)));
   LPT_HIP(c, hipMalloc(&c->dObjShade, oshade.size() * sizeof(ObjShade)));
   LPT_HIP(c, hipMalloc(&c->dVerts, std::max<size_t>(1, (size_t)nVerts) * sizeof(lpt_vertex)));
   LPT_HIP(c, hipMalloc(&dBase, baseColor.size() * sizeof(float)));
-  LPT_HIP(c, hipMemcpy(c->dTlas, tlas.data(), tlas.size() * sizeof(TNode), hipMemcpyHostToDevice));
-  LPT_HIP(c, hipMemcpy(c->dBlas, blas.data(), blas.size() * sizeof(TNode), hipMemcpyHostToDevice));
+  LPT_HIP(c, hipMemcpy(c->dNodes, nodes.data(), nodes.size() * sizeof(TNode), hipMemcpyHostToDevice));
   if (!tris.empty()) LPT_HIP(c, hipMemcpy(c->dTris, tris.data(), tris.size() * sizeof(Tri), hipMemcpyHostToDevice));
   LPT_HIP(c, hipMemcpy(c->dObjTrav, otrav.data(), otrav.size() * sizeof(ObjTrav), hipMemcpyHostToDevice));
   LPT_HIP(c, hipMemcpy(c->dObjShade, oshade.data(), oshade.size() * sizeof(ObjShade), hipMemcpyHostToDevice));
@@ -830,7 +934,10 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
   LPT_HIP(c, hipGetLastError());
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   (void)hipFree(dBase);
-  c->tlasRootRef = tlasRoot;
+  c->rootRef = sceneRoot;
+  c->nNodes = (uint32_t)order.size();
+  c->nTris = (uint32_t)tris.size();
+  c->nObjects = nObj;
   c->stackNeed = stackNeed;
   c->sceneLoaded = true;
   return LPT_OK;

@@ -1,5 +1,6 @@
 // Flat C entry points over the C++ host classes, for bindings (ctypes) and tests.
 // Every function catches C++ exceptions and reports them through an error string.
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <memory>
@@ -55,6 +56,12 @@ void* lpth_scene_load(const char* gltf_path, int builder, lpt_ctx* ctx) {
     handle->scene = scenes.at(0);
     handle->converter = std::make_unique<PTSceneConverter>(ctx);
     handle->converter->setMeshBuilder((PTSceneConverter::MeshBuilder)builder);
+    if (const char* e = std::getenv("LPT_BVH_CHILD_ORDER")) {
+      lsg::bvh::BuildOptions o;
+      o.childOrder = std::atoi(e);
+      if (const char* l = std::getenv("LPT_BVH_LEAF")) o.maxLeafSize = (uint32_t)std::atoi(l);
+      handle->converter->setBuildOptions(o);
+    }
     handle->converter->loadScene(handle->scene);
     h = handle.release();
   });

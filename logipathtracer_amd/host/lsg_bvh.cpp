@@ -286,12 +286,22 @@ class Builder {
       }
     }
     std::vector<PrimRef>().swap(refs);
-    uint32_t li = build(std::move(L), lb, depth + 1);
-    uint32_t ri = build(std::move(R), rb, depth + 1);
+    // The path tracer walks child y before child x, whatever the ray (shaders/path_tracing.comp:
+    // 159-171 pushes x then y and pops y).  childOrder decides which half becomes y.
+    bool swapHalves = false;
+    if (opt_.childOrder == 1) swapHalves = lb.area() > rb.area();       // larger box visited first
+    else if (opt_.childOrder == 2) swapHalves = lb.area() < rb.area();  // smaller box visited first
+    if (swapHalves) {
+      std::swap(L, R);
+      std::swap(lb, rb);
+    }
+    // the half visited first is stored right behind its parent
+    uint32_t yi = build(std::move(R), rb, depth + 1);
+    uint32_t xi = build(std::move(L), lb, depth + 1);
     Node<float>& node = bvh_->nodes_[idx];
     node.is_leaf = false;
-    node.child_indices.x = li;
-    node.child_indices.y = ri;
+    node.child_indices.x = xi;
+    node.child_indices.y = yi;
     return idx;
   }
 };

@@ -44,6 +44,9 @@ struct BuildOptions {
   // the best object split exceeds this fraction of the root's surface area.
   float splitAlpha = 1e-5f;
   bool spatialSplits = true;
+  // Which child is visited first by the (ray-independent) traversal order: 0 as split,
+  // 1 the child with the larger box, 2 the child with the smaller box.
+  int childOrder = 0;
 };
 
 // Binned surface-area-heuristic build over axis-aligned boxes (object splits only).

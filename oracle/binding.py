@@ -36,7 +36,7 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("hits", C.c_uint64), ("boxTests", C.c_uint64),
                 ("rootVisits", C.c_uint64), ("triTests", C.c_uint64), ("objectsEntered", C.c_uint64),
                 ("walkSteps", C.c_uint64), ("rands", C.c_uint64), ("maxStackTlas", C.c_uint32),
-                ("maxStackBlas", C.c_uint32), ("stackOverflow", C.c_uint32), ("pad", C.c_uint32)]
+                ("maxStackBlas", C.c_uint32), ("stackOverflow", C.c_uint32), ("maxSegmentSteps", C.c_uint32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "pad"}
@@ -115,7 +115,7 @@ def render_frames(scene, ubos, width, height, max_bounces, bsdf_mode=BSDF_HEITZ,
         if rc != 0:
             raise RuntimeError(f"lpto_render_frame failed with {rc}")
         for k, v in st.as_dict().items():
-            total[k] = max(total.get(k, 0), v) if k.startswith("maxStack") else total.get(k, 0) + v
+            total[k] = max(total.get(k, 0), v) if k.startswith("max") else total.get(k, 0) + v
     return accum, total
 
 

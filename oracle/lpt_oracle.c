@@ -614,6 +614,12 @@ void lpto_generate_ray(const lpto_ubo* ubo, int px, int py, int resx, int resy, 
   d[0] = r.direction.x; d[1] = r.direction.y; d[2] = r.direction.z;
 }
 
+/* Optional visit histograms (analysis aid): one counter per object-BVH / mesh-BVH node,
+ * incremented whenever traversal visits that node. */
+static uint32_t* g_hist_tlas = 0;
+static uint32_t* g_hist_blas = 0;
+void lpto_set_visit_histograms(uint32_t* tlas, uint32_t* blas) { g_hist_tlas = tlas; g_hist_blas = blas; }
+
 /* path_tracing.comp:130-173 */
 static void object_intersect(const lpto_scene* sc, const ray_t* ray, uint32_t objectIndex, isect_t* isect,
                              lpto_stats* st) {
@@ -634,6 +640,10 @@ static void object_intersect(const lpto_scene* sc, const ray_t* ray, uint32_t ob
   int idx = bvhOffset;
   while (idx > -1) {
     const lpto_bvh_node* node = &sc->meshBvh[idx];
+    if (g_hist_blas) {
+#pragma omp atomic
+      g_hist_blas[idx]++;
+    }
     if (node->isLeaf) {
       for (uint32_t i = node->indices[0]; i < node->indices[1]; i++) {
         uint32_t firstVertexIdx = verticesOffset + 3u * i;
@@ -679,6 +689,10 @@ static isect_t scene_intersect(const lpto_scene* sc, const ray_t* ray, lpto_stat
   int idx = 0;
   while (idx > -1) {
     const lpto_bvh_node* node = &sc->objectBvh[idx];
+    if (g_hist_tlas) {
+#pragma omp atomic
+      g_hist_tlas[idx]++;
+    }
     if (node->isLeaf) {
       for (uint32_t i = node->indices[0]; i < node->indices[1]; i++) {
         object_intersect(sc, ray, i, &isect, st);
@@ -755,7 +769,10 @@ static v3 trace_ray(const lpto_scene* sc, path_ctx* c, ray_t ray, int maxBounces
 
   for (uint32_t bounce = 0; bounce < (uint32_t)maxBounces; bounce++) {
     st->segments++;
+    const uint64_t stepsBefore = st->boxTests / 2 + st->triTests + st->objectsEntered;
     isect_t isect = scene_intersect(sc, &ray, st);
+    const uint64_t steps = st->boxTests / 2 + st->triTests + st->objectsEntered - stepsBefore;
+    if (steps > st->maxSegmentSteps) st->maxSegmentSteps = (uint32_t)steps;
 
     if (isect.distance == LPT_INFINITY) { /* :220-223 — assignment, not accumulation */
       accColor = scale(mask, 0.2f);
@@ -880,6 +897,7 @@ int lpto_render_frame(const lpto_scene* sc, const lpto_ubo* ubo, const lpto_para
       if (st.maxStackTlas > total.maxStackTlas) total.maxStackTlas = st.maxStackTlas;
       if (st.maxStackBlas > total.maxStackBlas) total.maxStackBlas = st.maxStackBlas;
       total.stackOverflow |= st.stackOverflow;
+      if (st.maxSegmentSteps > total.maxSegmentSteps) total.maxSegmentSteps = st.maxSegmentSteps;
     }
   }
   if (stats) *stats = total;

@@ -118,7 +118,7 @@ typedef struct {
   uint32_t maxStackTlas;
   uint32_t maxStackBlas;
   uint32_t stackOverflow;  /* non-zero if a traversal needed more than LPTO_STACK entries */
-  uint32_t pad;
+  uint32_t maxSegmentSteps; /* largest number of traversal steps (node visits + triangle tests + objects) of one segment */
 } lpto_stats;
 
 #define LPTO_STACK 128
@@ -168,6 +168,10 @@ int lpto_scene_intersect(const lpto_scene* scene, const float o[3], const float 
  * (no BVH); used to check BVH builders. */
 int lpto_brute_force_intersect(const lpto_scene* scene, const float o[3], const float d[3], float* t,
                                uint32_t* objectIndex, uint32_t* primitiveIndex);
+
+/* Analysis aid: when non-NULL, every visit of object-BVH node i / mesh-BVH node j increments
+ * tlas[i] / blas[j].  Pass NULLs to switch it off (the default). */
+void lpto_set_visit_histograms(uint32_t* tlas, uint32_t* blas);
 
 /* The fixed transcendental algorithms of the arithmetic contract. */
 float lpto_sin(float x);
