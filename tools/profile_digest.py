@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/profile_<tag>/ into the files kept under profiles/.
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the bench command
+  profiles/<tag>_pmc.txt            per-kernel PMC totals and derived ratios
+  profiles/extend_traffic.json      HBM bytes per k_extend launch, read by bench.py (roofline.traffic)
+
+HBM bytes follow the gfx950 rule for rocprofv3: FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE counts
+128-byte read requests as 64 bytes, so reads are doubled: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import csv
+import glob
+import io
+import json
+import os
+import shutil
+import sys
+from contextlib import redirect_stdout
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_summary  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"profile_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "bench_traced.json")):
+    shutil.copy(os.path.join(src, "bench_traced.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+
+buf = io.StringIO()
+with redirect_stdout(buf):
+    pmc_summary.main(src)
+open(os.path.join(dst, f"{tag}_pmc.txt"), "w").write(buf.getvalue())
+
+
+def per_dispatch(counter, kernel_substr):
+    tot, n = 0.0, 0
+    for path in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                tot += float(row["Counter_Value"])
+                n += 1
+    return (tot / n if n else None), n
+
+
+fetch, nf = per_dispatch("FETCH_SIZE", "k_extend")
+write, nw = per_dispatch("WRITE_SIZE", "k_extend")
+if fetch is not None and write is not None:
+    traffic = {
+        "kernel": "k_extend",
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+        "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write, "launches": nf,
+        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+        "rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B reads as 64 B)",
+    }
+    json.dump(traffic, open(os.path.join(dst, "extend_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+print(buf.getvalue()[:3000])
