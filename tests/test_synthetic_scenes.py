@@ -32,7 +32,7 @@ def test_outside_synth_is_deterministic_and_converts(small_outside, tmp_path):
     assert 60 <= len(s.objects) <= 80  # the reference scene has 70 primitives
     assert abs(s.fov_y - 0.7696) < 1e-6
     assert (s.objects["transmissionFactor"] > 0.9).sum() == 1 and (s.objects["emissionFactor"].sum(axis=1) > 0).sum() == 2
-    assert sorted(set(np.round(s.objects["metallicFactor"], 3).tolist())) == [0.0, 0.5, 0.7]
+    assert sorted(set(np.round(s.objects["metallicFactor"].astype(np.float64), 3).tolist())) == [0.0, 0.5, 0.7]
     # the oracle renders it without overflowing its stack; most rays hit (closed sky shell)
     osc = O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
     img, st = O.render_frames(osc, L.frame_ubos(s.camera_world, s.fov_y, 1), 64, 36, 4)
