@@ -165,6 +165,77 @@ __device__ __forceinline__ f3 diffuse_bsdf(Rng& rng, f3 F0, f3 viewDir, float ro
   return energy;
 }
 
+// The three random walks above in ONE loop, for kernels where neighbouring lanes hold
+// different lobes: the costly parts of an order (height sample, visible-normal sample) are
+// the same code for every lobe and run with all lanes; only the short phase functions are
+// lobe-specific.  Per lane, the operations and the random numbers drawn are exactly those of
+// diffuse_bsdf / conductor_brdf / dielectric_bsdf (negations are exact, so the mirrored
+// height sampling of heitz/BSDF.glsl:194 folds into sign flips).
+__device__ __forceinline__ f3 heitz_bsdf_unified(Rng& rng, uint32_t kind, f3 F0, f3 viewDir, float roughness,
+                                                 float ior, bool outsideIn, f3& lightDir) {
+  const float alpha = roughness * roughness;
+  f3 energy{1.0f, 1.0f, 1.0f};
+  lightDir = -viewDir;
+  float height = 0.0f;
+  const float iorOut = outsideIn ? 1.0f : ior;
+  const float iorIn = outsideIn ? ior : 1.0f;
+  bool outside = true;  // side of the microsurface the walk is on (dielectric only)
+  int order = 0;
+  for (; order < kHeitzMaxOrder; ++order) {
+    const bool flip = (kind == kTrans) && !outside;
+    const f3 dirH = flip ? -lightDir : lightDir;
+    const float hs = sample_ggx_height(rng, dirH, flip ? -height : height, alpha);
+    height = flip ? -hs : hs;
+    if (flip ? (height < 0.0f) : (height > 0.0f)) break;
+    const f3 vd = -lightDir;
+    const f3 m = sample_ggx_vndf(rng, vd, alpha);
+    if (kind == kMetallic) {
+      const float vdoth = clamp_num(dot3(vd, m), 0.0f, 1.0f);
+      lightDir = (m * 2.0f) * vdoth - vd;
+      energy = energy * F0;
+    } else if (kind == kDiff) {
+      f3 u = (m.z < 1.0f) ? normalize3(cross3(f3{0.0f, 0.0f, 1.0f}, m)) : f3{1.0f, 0.0f, 0.0f};
+      f3 v = cross3(m, u);
+      float R1 = 2.0f * rand01(rng) - 1.0f;
+      float R2 = 2.0f * rand01(rng) - 1.0f;
+      float phi, R;
+      if (R1 == 0.0f && R2 == 0.0f) {
+        R = 0.0f;
+        phi = 0.0f;
+      } else if (R1 * R1 > R2 * R2) {
+        R = R1;
+        phi = (kPi / 4.0f) * (R2 / R1);
+      } else {
+        R = R2;
+        phi = (kPi / 2.0f) - (R1 / R2) * (kPi / 4.0f);
+      }
+      float sn, cs;
+      sincos_fixed(phi, sn, cs);
+      float x = R * cs;
+      float y = R * sn;
+      float z = __builtin_sqrtf(max_num(0.0f, (1.0f - x * x) - y * y));
+      lightDir = (u * x + v * y) + m * z;
+      energy = energy * F0;
+    } else {
+      const float vdoth = dot3(vd, m);
+      const float eta = outside ? iorIn / iorOut : iorOut / iorIn;
+      const float F = fresnel_dielectric(vdoth, eta);
+      if (rand01(rng) < F) {
+        lightDir = (m * 2.0f) * vdoth - vd;
+      } else {
+        outside = !outside;
+        lightDir = normalize3(refract_eta(vd, m, eta));
+      }
+    }
+  }
+  if (kind == kTrans) return F0;  // heitz/BSDF.glsl:208
+  if (kind == kDiff && order >= kHeitzMaxOrder) {  // heitz/BSDF.glsl:269-272
+    lightDir = f3{0.0f, 0.0f, 1.0f};
+    return f3{0.0f, 0.0f, 0.0f};
+  }
+  return energy;
+}
+
 // ---- basic family -------------------------------------------------------------
 
 __device__ __forceinline__ f3 glsl_reflect(f3 I, f3 N) { return I - N * (2.0f * dot3(N, I)); }

@@ -260,6 +260,9 @@ __device__ __forceinline__ f3 barycentric(f3 point, f3 v0, f3 v1, f3 v2) {
 // One iteration of traceRay's loop after the intersection is known
 // (shaders/path_tracing.comp:219-323).  Returns true if the path goes on to
 // bounce+1; otherwise `sample` holds the path's radiance.
+// UNIFIED selects the single-loop form of the three Heitz walks (heitz_bsdf_unified), which
+// keeps lanes with different lobes in step; the per-lobe functions give the same values.
+template <bool UNIFIED>
 __device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& hit, uint32_t bounce,
                                           uint32_t maxBounces, int bsdfMode, f3& sample) {
   if (hit.t == kInfinity) {  // :220-223 — assignment: radiance gathered so far is dropped
@@ -295,14 +298,16 @@ __device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& 
   f3 viewDir{dot3(nd, u), dot3(nd, v), dot3(nd, ff)};
   f3 lightDir{0.0f, 0.0f, 0.0f};
 
-  if (interaction == kDiff) {
+  const bool outside = dot3(normal, nd) > 0.0f;  // :304 — the unflipped normal (used by the dielectric lobe)
+  if (UNIFIED && bsdfMode == LPT_BSDF_HEITZ) {
+    p.mask = p.mask * heitz_bsdf_unified(p.rng, interaction, baseLinear, viewDir, roughness, ior, outside, lightDir);
+  } else if (interaction == kDiff) {
     p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ ? diffuse_bsdf(p.rng, baseLinear, viewDir, roughness, lightDir)
                                                   : basic_diffuse(p.rng, baseLinear, lightDir));
   } else if (interaction == kMetallic) {
     p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ ? conductor_brdf(p.rng, baseLinear, viewDir, roughness, lightDir)
                                                   : basic_specular(baseLinear, viewDir, lightDir));
   } else if (interaction == kTrans) {
-    bool outside = dot3(normal, nd) > 0.0f;  // :304 — the unflipped normal
     p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ
                            ? dielectric_bsdf(p.rng, baseLinear, viewDir, roughness, ior, lightDir, outside)
                            : basic_transmittance(p.rng, baseLinear, viewDir, transmission, ior, outside, lightDir));

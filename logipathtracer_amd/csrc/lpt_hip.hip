@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
       pid = as_uint(o.w);
       Hit hit{h.x, as_uint(h.y), as_uint(h.z)};
       f3 s;
-      alive = shade_hit(sc, p, hit, bounce, maxBounces, bsdfMode, s);
+      alive = shade_hit<true>(sc, p, hit, bounce, maxBounces, bsdfMode, s);
       if (!alive) samples[pid] = make_float4(s.x, s.y, s.z, 0.0f);
     }
     uint32_t dst = block_append(alive, countOut, lds);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DScene sc, Partition P, l
     for (uint32_t bounce = 0; bounce < maxBounces; ++bounce) {
       ++segments;
       Hit h = intersect_scene(sc, p.o, p.d, &stack[threadIdx.x], kBlock);
-      if (!shade_hit(sc, p, h, bounce, maxBounces, bsdfMode, s)) break;
+      if (!shade_hit<false>(sc, p, h, bounce, maxBounces, bsdfMode, s)) break;
     }
     if (ubo.reset) {
       accum[slot] = make_float4(s.x, s.y, s.z, 1.0f);
