@@ -35,9 +35,13 @@ __host__ __device__ inline uint32_t leaf_count(uint32_t ref) { return (ref >> 25
 // Derived inner node, 64 B: the boxes of BOTH children (the interchange node,
 // path_tracing.comp:29-39, stores its own box, so a visit there costs three node
 // fetches; here it costs one).
+// Components are interleaved child0/child1 so that one 16-byte load yields two aligned
+// pairs for packed-f32 arithmetic: [mn.x0 mn.x1 mn.y0 mn.y1] [mn.z0 mn.z1 mx.x0 mx.x1]
+// [mx.y0 mx.y1 mx.z0 mx.z1] [ref0 ref1 - -].
 struct alignas(16) TNode {
-  float c0min[3], c0max[3];
-  float c1min[3], c1max[3];
+  float mnx[2], mny[2];
+  float mnz[2], mxx[2];
+  float mxy[2], mxz[2];
   uint32_t ref0, ref1;
   uint32_t pad[2];
 };
@@ -118,6 +122,29 @@ __device__ __forceinline__ bool box_test(f3 o, f3 inv, const float* mn, const fl
   return t1 > 0.0f;
 }
 
+// The same slab test for the two children of a derived node at once.  Subtractions and
+// multiplications run as packed-f32 operations (v_pk_add_f32 / v_pk_mul_f32: two IEEE
+// single-precision results per lane and instruction, rounded exactly like the scalar forms),
+// halving their instruction count; min/max and the compares stay scalar.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void box_test_pair(f3 o, f3 inv, float4 q0, float4 q1, float4 q2, float dist, bool& h0,
+                                              bool& h1) {
+  const v2f ox{o.x, o.x}, oy{o.y, o.y}, oz{o.z, o.z};
+  const v2f ix{inv.x, inv.x}, iy{inv.y, inv.y}, iz{inv.z, inv.z};
+  const v2f nx = (v2f{q0.x, q0.y} - ox) * ix, ny = (v2f{q0.z, q0.w} - oy) * iy, nz = (v2f{q1.x, q1.y} - oz) * iz;
+  const v2f fx = (v2f{q1.z, q1.w} - ox) * ix, fy = (v2f{q2.x, q2.y} - oy) * iy, fz = (v2f{q2.z, q2.w} - oz) * iz;
+  {
+    float t0 = max_num(max_num(min_num(nx.x, fx.x), min_num(ny.x, fy.x)), min_num(nz.x, fz.x));
+    float t1 = min_num(min_num(max_num(nx.x, fx.x), max_num(ny.x, fy.x)), max_num(nz.x, fz.x));
+    h0 = !(t0 > t1) && ((t0 > 0.0f) ? (t0 < dist) : (t1 > 0.0f));
+  }
+  {
+    float t0 = max_num(max_num(min_num(nx.y, fx.y), min_num(ny.y, fy.y)), min_num(nz.y, fz.y));
+    float t1 = min_num(min_num(max_num(nx.y, fx.y), max_num(ny.y, fy.y)), max_num(nz.y, fz.y));
+    h1 = !(t0 > t1) && ((t0 > 0.0f) ? (t0 < dist) : (t1 > 0.0f));
+  }
+}
+
 // shaders/common/ray.glsl:63-82 (Moeller-Trumbore, no culling, no parallel check)
 __device__ __forceinline__ float tri_test(f3 o, f3 d, f3 v0, f3 e1, f3 e2) {
   f3 pvec = cross3(d, e2);
@@ -162,10 +189,8 @@ __device__ __forceinline__ Hit intersect_scene(const DScene& sc, f3 wo, f3 wd, u
     if (!(cur & kRefLeafBit)) {
       const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
       float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-      float c0mn[3] = {q0.x, q0.y, q0.z}, c0mx[3] = {q0.w, q1.x, q1.y};
-      float c1mn[3] = {q1.z, q1.w, q2.x}, c1mx[3] = {q2.y, q2.z, q2.w};
-      bool h0 = box_test(co, cinv, c0mn, c0mx, hit.t);
-      bool h1 = box_test(co, cinv, c1mn, c1mx, hit.t);
+      bool h0, h1;
+      box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
       uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
       if (h1) {
         if (h0) stk[(sp++) * stride] = r0;

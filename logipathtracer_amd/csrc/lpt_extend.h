@@ -139,10 +139,8 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
           const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
           q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
         }
-        const float c0mn[3] = {q0.x, q0.y, q0.z}, c0mx[3] = {q0.w, q1.x, q1.y};
-        const float c1mn[3] = {q1.z, q1.w, q2.x}, c1mx[3] = {q2.y, q2.z, q2.w};
-        const bool h0 = box_test(co, cinv, c0mn, c0mx, hit.t);
-        const bool h1 = box_test(co, cinv, c1mn, c1mx, hit.t);
+        bool h0, h1;
+        box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
         const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
         if (h0 && h1) stk[(sp++) * BLOCK] = r0;
         cur = h1 ? r1 : r0;
@@ -193,10 +191,11 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
           co = xform_point(rows, wo);
           cd = xform_dir(rows, wd);
-          cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
           curObj = first;
           inObj = true;
           cur = as_uint(r3.x);
+          // the reciprocal direction only feeds box tests: not needed when the mesh tree is one leaf
+          if (!(cur & kRefLeafBit)) cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
         }
         stepped = true;
       }

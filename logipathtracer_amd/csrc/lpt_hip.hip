@@ -550,6 +550,8 @@ int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* c
   // persistent grid sized by LDS residency (160 KiB per CU)
   const size_t ldsBytes = sizeof(ExtendShared<S, BLOCK, KN, KT, KO>);
   int perCU = std::max<int>(1, std::min<int>(2048 / BLOCK, (int)(160 * 1024 / ldsBytes)));
+  static const int capPerCU = std::getenv("LPT_EXTEND_BLOCKS_PER_CU") ? std::atoi(std::getenv("LPT_EXTEND_BLOCKS_PER_CU")) : 0;
+  if (capPerCU > 0) perCU = std::min(perCU, capPerCU);
   size_t need = (maxItems + BLOCK - 1) / BLOCK;
   int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
   hipLaunchKernelGGL((k_extend<S, BLOCK, KN, KT, KO>), dim3(grid), dim3(BLOCK), 0, c->stream, device_scene(c), q.o,
@@ -564,6 +566,10 @@ int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t*
   // 512 triangles in LDS.  LPT_EXTEND_VARIANT=1 selects the LDS-cached form for experiments.
   static const int variant = std::getenv("LPT_EXTEND_VARIANT") ? std::atoi(std::getenv("LPT_EXTEND_VARIANT")) : 0;
   if (variant == 1 && c->stackNeed <= 20) return launch_extend<20, 1024, 768, 512, 32>(c, q, count, cursor, maxItems);
+  if (variant == 2 && c->stackNeed <= 20) return launch_extend<20, 256, 16, 0, 16>(c, q, count, cursor, maxItems);
+  if (variant == 3 && c->stackNeed <= 20) return launch_extend<20, 256, 32, 16, 16>(c, q, count, cursor, maxItems);
+  if (variant == 4 && c->stackNeed <= 20) return launch_extend<20, 512, 128, 64, 16>(c, q, count, cursor, maxItems);
+  if (variant == 5 && c->stackNeed <= 20) return launch_extend<20, 512, 256, 128, 32>(c, q, count, cursor, maxItems);
   if (c->stackNeed <= 16) return launch_extend<16, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
   if (c->stackNeed <= 20) return launch_extend<20, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
   if (c->stackNeed <= 24) return launch_extend<24, 256, 0, 0, 0>(c, q, count, cursor, maxItems);
@@ -881,10 +887,10 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
       if (pl.kind == 0) refs[k] = ch[k]->isLeaf ? objLeafRef(*ch[k]) : (uint32_t)newT[ci];
       else refs[k] = ch[k]->isLeaf ? meshLeafRef(ci) : (uint32_t)newB[ci];
     }
-    std::memcpy(t.c0min, ch[0]->minCorner, 12);
-    std::memcpy(t.c0max, ch[0]->maxCorner, 12);
-    std::memcpy(t.c1min, ch[1]->minCorner, 12);
-    std::memcpy(t.c1max, ch[1]->maxCorner, 12);
+    for (int k = 0; k < 2; ++k) {
+      t.mnx[k] = ch[k]->minCorner[0]; t.mny[k] = ch[k]->minCorner[1]; t.mnz[k] = ch[k]->minCorner[2];
+      t.mxx[k] = ch[k]->maxCorner[0]; t.mxy[k] = ch[k]->maxCorner[1]; t.mxz[k] = ch[k]->maxCorner[2];
+    }
     t.ref0 = refs[0];
     t.ref1 = refs[1];
     nodes[i] = t;
