@@ -8,8 +8,8 @@ CSRC    := logipathtracer_amd/csrc
 HOST    := logipathtracer_amd/host
 
 # Bit-level parity with the CPU oracle needs: no FMA contraction, IEEE divide/sqrt, no fast-math.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
-            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(HIPFLAGS_EXTRA) -ffp-contract=off \
+            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-pass-failed
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra
 
 HOST_SRCS := $(HOST)/lsg_min.cpp $(HOST)/lsg_bvh.cpp $(HOST)/pt_scene_converter.cpp \

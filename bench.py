@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--spp-per-step", type=int, default=32, help="frames per step and per GPU")
+    ap.add_argument("--spp-per-step", type=int, default=128, help="frames per step and per GPU")
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_box.gltf"))
@@ -207,7 +207,7 @@ def main():
                             f"Heitz BSDF, {spp_step} spp per step ({args.spp_per_step} per GPU)",
                 "spp_per_step": spp_step, "tile": args.tile if world > 1 else None,
                 "builder": ["split_bvh", "binned_sah", "lbvh_gpu"][args.builder],
-                "pipeline": ["wavefront", "megakernel"][args.pipeline],
+                "pipeline": ["wavefront", "megakernel", "persistent"][args.pipeline],
             },
             "nominal_msamples_per_s": nominal / elapsed / 1e6,
             "traced_segments": seg_total,

@@ -90,7 +90,7 @@ typedef enum lpt_status {
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
 /* Kernel organisation.  Both produce identical pixels. */
-enum { LPT_PIPELINE_WAVEFRONT = 0, LPT_PIPELINE_MEGAKERNEL = 1 };
+enum { LPT_PIPELINE_WAVEFRONT = 0, LPT_PIPELINE_MEGAKERNEL = 1, LPT_PIPELINE_PERSISTENT = 2 };
 /* Mesh BVH builders offered by lpt_build_mesh_bvh. */
 enum { LPT_BVH_LBVH = 0 };
 

@@ -165,75 +165,103 @@ __device__ __forceinline__ f3 diffuse_bsdf(Rng& rng, f3 F0, f3 viewDir, float ro
   return energy;
 }
 
-// The three random walks above in ONE loop, for kernels where neighbouring lanes hold
+// The three random walks above as ONE step function, for kernels where neighbouring lanes hold
 // different lobes: the costly parts of an order (height sample, visible-normal sample) are
 // the same code for every lobe and run with all lanes; only the short phase functions are
 // lobe-specific.  Per lane, the operations and the random numbers drawn are exactly those of
 // diffuse_bsdf / conductor_brdf / dielectric_bsdf (negations are exact, so the mirrored
 // height sampling of heitz/BSDF.glsl:194 folds into sign flips).
-__device__ __forceinline__ f3 heitz_bsdf_unified(Rng& rng, uint32_t kind, f3 F0, f3 viewDir, float roughness,
-                                                 float ior, bool outsideIn, f3& lightDir) {
-  const float alpha = roughness * roughness;
-  f3 energy{1.0f, 1.0f, 1.0f};
-  lightDir = -viewDir;
-  float height = 0.0f;
-  const float iorOut = outsideIn ? 1.0f : ior;
-  const float iorIn = outsideIn ? ior : 1.0f;
-  bool outside = true;  // side of the microsurface the walk is on (dielectric only)
-  int order = 0;
-  for (; order < kHeitzMaxOrder; ++order) {
-    const bool flip = (kind == kTrans) && !outside;
-    const f3 dirH = flip ? -lightDir : lightDir;
-    const float hs = sample_ggx_height(rng, dirH, flip ? -height : height, alpha);
-    height = flip ? -hs : hs;
-    if (flip ? (height < 0.0f) : (height > 0.0f)) break;
-    const f3 vd = -lightDir;
-    const f3 m = sample_ggx_vndf(rng, vd, alpha);
-    if (kind == kMetallic) {
-      const float vdoth = clamp_num(dot3(vd, m), 0.0f, 1.0f);
-      lightDir = (m * 2.0f) * vdoth - vd;
-      energy = energy * F0;
-    } else if (kind == kDiff) {
-      f3 u = (m.z < 1.0f) ? normalize3(cross3(f3{0.0f, 0.0f, 1.0f}, m)) : f3{1.0f, 0.0f, 0.0f};
-      f3 v = cross3(m, u);
-      float R1 = 2.0f * rand01(rng) - 1.0f;
-      float R2 = 2.0f * rand01(rng) - 1.0f;
-      float phi, R;
-      if (R1 == 0.0f && R2 == 0.0f) {
-        R = 0.0f;
-        phi = 0.0f;
-      } else if (R1 * R1 > R2 * R2) {
-        R = R1;
-        phi = (kPi / 4.0f) * (R2 / R1);
-      } else {
-        R = R2;
-        phi = (kPi / 2.0f) - (R1 / R2) * (kPi / 4.0f);
-      }
-      float sn, cs;
-      sincos_fixed(phi, sn, cs);
-      float x = R * cs;
-      float y = R * sn;
-      float z = __builtin_sqrtf(max_num(0.0f, (1.0f - x * x) - y * y));
-      lightDir = (u * x + v * y) + m * z;
-      energy = energy * F0;
+struct HeitzWalk {
+  f3 lightDir;
+  float height;
+  f3 energy;
+  int order;
+  bool outside;  // side of the microsurface the walk is on (dielectric only)
+};
+
+__device__ __forceinline__ void heitz_walk_begin(HeitzWalk& w, f3 viewDir) {
+  w.lightDir = -viewDir;
+  w.height = 0.0f;
+  w.energy = f3{1.0f, 1.0f, 1.0f};
+  w.order = 0;
+  w.outside = true;
+}
+
+// One scattering order: the body of the `for (order ...)` loops of heitz/BSDF.glsl:116-135,
+// :183-206 and :249-266.  Returns true when the walk is over (it left the microsurface or
+// reached the order cap).  iorOut/iorIn are the indices on the ray's side / the far side.
+__device__ __forceinline__ bool heitz_walk_step(Rng& rng, HeitzWalk& w, uint32_t kind, f3 F0, float alpha,
+                                                float iorOut, float iorIn) {
+  const bool flip = (kind == kTrans) && !w.outside;
+  const f3 dirH = flip ? -w.lightDir : w.lightDir;
+  const float hs = sample_ggx_height(rng, dirH, flip ? -w.height : w.height, alpha);
+  w.height = flip ? -hs : hs;
+  if (flip ? (w.height < 0.0f) : (w.height > 0.0f)) return true;
+  const f3 vd = -w.lightDir;
+  const f3 m = sample_ggx_vndf(rng, vd, alpha);
+  if (kind == kMetallic) {
+    const float vdoth = clamp_num(dot3(vd, m), 0.0f, 1.0f);
+    w.lightDir = (m * 2.0f) * vdoth - vd;
+    w.energy = w.energy * F0;
+  } else if (kind == kDiff) {
+    f3 u = (m.z < 1.0f) ? normalize3(cross3(f3{0.0f, 0.0f, 1.0f}, m)) : f3{1.0f, 0.0f, 0.0f};
+    f3 v = cross3(m, u);
+    float R1 = 2.0f * rand01(rng) - 1.0f;
+    float R2 = 2.0f * rand01(rng) - 1.0f;
+    float phi, R;
+    if (R1 == 0.0f && R2 == 0.0f) {
+      R = 0.0f;
+      phi = 0.0f;
+    } else if (R1 * R1 > R2 * R2) {
+      R = R1;
+      phi = (kPi / 4.0f) * (R2 / R1);
     } else {
-      const float vdoth = dot3(vd, m);
-      const float eta = outside ? iorIn / iorOut : iorOut / iorIn;
-      const float F = fresnel_dielectric(vdoth, eta);
-      if (rand01(rng) < F) {
-        lightDir = (m * 2.0f) * vdoth - vd;
-      } else {
-        outside = !outside;
-        lightDir = normalize3(refract_eta(vd, m, eta));
-      }
+      R = R2;
+      phi = (kPi / 2.0f) - (R1 / R2) * (kPi / 4.0f);
+    }
+    float sn, cs;
+    sincos_fixed(phi, sn, cs);
+    float x = R * cs;
+    float y = R * sn;
+    float z = __builtin_sqrtf(max_num(0.0f, (1.0f - x * x) - y * y));
+    w.lightDir = (u * x + v * y) + m * z;
+    w.energy = w.energy * F0;
+  } else {
+    const float vdoth = dot3(vd, m);
+    const float eta = w.outside ? iorIn / iorOut : iorOut / iorIn;
+    const float F = fresnel_dielectric(vdoth, eta);
+    if (rand01(rng) < F) {
+      w.lightDir = (m * 2.0f) * vdoth - vd;
+    } else {
+      w.outside = !w.outside;
+      w.lightDir = normalize3(refract_eta(vd, m, eta));
     }
   }
+  ++w.order;
+  return w.order >= kHeitzMaxOrder;
+}
+
+// Weight and sampled direction of a finished walk.
+__device__ __forceinline__ f3 heitz_walk_result(const HeitzWalk& w, uint32_t kind, f3 F0, f3& lightDir) {
+  lightDir = w.lightDir;
   if (kind == kTrans) return F0;  // heitz/BSDF.glsl:208
-  if (kind == kDiff && order >= kHeitzMaxOrder) {  // heitz/BSDF.glsl:269-272
+  if (kind == kDiff && w.order >= kHeitzMaxOrder) {  // heitz/BSDF.glsl:269-272
     lightDir = f3{0.0f, 0.0f, 1.0f};
     return f3{0.0f, 0.0f, 0.0f};
   }
-  return energy;
+  return w.energy;
+}
+
+__device__ __forceinline__ f3 heitz_bsdf_unified(Rng& rng, uint32_t kind, f3 F0, f3 viewDir, float roughness,
+                                                 float ior, bool outsideIn, f3& lightDir) {
+  const float alpha = roughness * roughness;
+  const float iorOut = outsideIn ? 1.0f : ior;
+  const float iorIn = outsideIn ? ior : 1.0f;
+  HeitzWalk w;
+  heitz_walk_begin(w, viewDir);
+  while (!heitz_walk_step(rng, w, kind, F0, alpha, iorOut, iorIn)) {
+  }
+  return heitz_walk_result(w, kind, F0, lightDir);
 }
 
 // ---- basic family -------------------------------------------------------------

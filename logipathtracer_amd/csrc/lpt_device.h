@@ -283,13 +283,22 @@ __device__ __forceinline__ f3 barycentric(f3 point, f3 v0, f3 v1, f3 v2) {
 }
 
 // One iteration of traceRay's loop after the intersection is known
-// (shaders/path_tracing.comp:219-323).  Returns true if the path goes on to
-// bounce+1; otherwise `sample` holds the path's radiance.
-// UNIFIED selects the single-loop form of the three Heitz walks (heitz_bsdf_unified), which
-// keeps lanes with different lobes in step; the per-lobe functions give the same values.
-template <bool UNIFIED>
-__device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& hit, uint32_t bounce,
-                                          uint32_t maxBounces, int bsdfMode, f3& sample) {
+// (shaders/path_tracing.comp:219-323), in two halves around the BSDF sampling so that
+// kernels may run the Heitz random walk as separately scheduled steps.
+
+// What the BSDF sampling and the rest of the iteration need from the hit surface.
+struct Surface {
+  f3 u, v, ff;        // shading frame; ff = front-facing normal
+  f3 posW;            // hit point, the next ray's origin
+  f3 viewDir;         // -ray direction in the shading frame
+  f3 baseLinear;
+  float roughness, transmission, ior;
+  uint32_t interaction;
+  bool outside;       // ray arrives on the side the unflipped normal points to (:304)
+};
+
+// :219-304.  Returns false on a miss; `sample` then holds the path's radiance.
+__device__ __forceinline__ bool shade_begin(const DScene& sc, Path& p, const Hit& hit, Surface& sf, f3& sample) {
   if (hit.t == kInfinity) {  // :220-223 — assignment: radiance gathered so far is dropped
     sample = p.mask * 0.2f;
     return false;
@@ -298,48 +307,50 @@ __device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& 
   float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3], s4 = sq[4], s5 = sq[5], s6 = sq[6], s7 = sq[7];
   float inv[12] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
   float nrm[9] = {s3.x, s3.y, s3.z, s3.w, s4.x, s4.y, s4.z, s4.w, s5.x};
-  f3 baseLinear{s5.y, s5.z, s5.w};
+  sf.baseLinear = f3{s5.y, s5.z, s5.w};
   f3 emission{s6.x, s6.y, s6.z};
-  float roughness = s6.w, metallic = s7.x, transmission = s7.y, ior = s7.z;
+  sf.roughness = s6.w;
+  float metallic = s7.x;
+  sf.transmission = s7.y;
+  sf.ior = s7.z;
 
   const float4* vq = reinterpret_cast<const float4*>(sc.verts + hit.prim);
   float4 p0 = vq[0], n0 = vq[1], p1 = vq[3], n1 = vq[4], p2 = vq[6], n2 = vq[7];
 
   f3 oo = xform_point(inv, p.o);
   f3 od = xform_dir(inv, p.d);
-  f3 posW = p.o + p.d * hit.t;
+  sf.posW = p.o + p.d * hit.t;
   f3 bary = barycentric(oo + od * hit.t, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z});
 
-  uint32_t interaction = pick_interaction(p.rng, metallic, transmission);  // :266
-  p.acc = p.acc + p.mask * emission;                                       // :269
+  sf.interaction = pick_interaction(p.rng, metallic, sf.transmission);  // :266
+  p.acc = p.acc + p.mask * emission;                                    // :269
 
   f3 nsum = (f3{n0.x, n0.y, n0.z} * bary.x + f3{n1.x, n1.y, n1.z} * bary.y) + f3{n2.x, n2.y, n2.z} * bary.z;
   f3 normal = normalize3(xform_mat3(nrm, nsum));  // :272 (mat3(worldMatrix), not inverse-transpose)
-  f3 ff = (dot3(normal, p.d) < 0.0f) ? normal : normal * -1.0f;
-  f3 axis = (__builtin_fabsf(ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
-  f3 u = normalize3(cross3(axis, ff));
-  f3 v = cross3(ff, u);
+  sf.ff = (dot3(normal, p.d) < 0.0f) ? normal : normal * -1.0f;
+  f3 axis = (__builtin_fabsf(sf.ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
+  sf.u = normalize3(cross3(axis, sf.ff));
+  sf.v = cross3(sf.ff, sf.u);
   f3 nd = -p.d;
-  f3 viewDir{dot3(nd, u), dot3(nd, v), dot3(nd, ff)};
-  f3 lightDir{0.0f, 0.0f, 0.0f};
+  sf.viewDir = f3{dot3(nd, sf.u), dot3(nd, sf.v), dot3(nd, sf.ff)};
+  sf.outside = dot3(normal, nd) > 0.0f;
+  return true;
+}
 
-  const bool outside = dot3(normal, nd) > 0.0f;  // :304 — the unflipped normal (used by the dielectric lobe)
-  if (UNIFIED && bsdfMode == LPT_BSDF_HEITZ) {
-    p.mask = p.mask * heitz_bsdf_unified(p.rng, interaction, baseLinear, viewDir, roughness, ior, outside, lightDir);
-  } else if (interaction == kDiff) {
-    p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ ? diffuse_bsdf(p.rng, baseLinear, viewDir, roughness, lightDir)
-                                                  : basic_diffuse(p.rng, baseLinear, lightDir));
-  } else if (interaction == kMetallic) {
-    p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ ? conductor_brdf(p.rng, baseLinear, viewDir, roughness, lightDir)
-                                                  : basic_specular(baseLinear, viewDir, lightDir));
-  } else if (interaction == kTrans) {
-    p.mask = p.mask * (bsdfMode == LPT_BSDF_HEITZ
-                           ? dielectric_bsdf(p.rng, baseLinear, viewDir, roughness, ior, lightDir, outside)
-                           : basic_transmittance(p.rng, baseLinear, viewDir, transmission, ior, outside, lightDir));
-  }
+// The basic family's sampling (shaders/basic/BSDF.glsl), selected by the lobe.
+__device__ __forceinline__ f3 basic_bsdf(Rng& rng, const Surface& sf, f3& lightDir) {
+  if (sf.interaction == kDiff) return basic_diffuse(rng, sf.baseLinear, lightDir);
+  if (sf.interaction == kMetallic) return basic_specular(sf.baseLinear, sf.viewDir, lightDir);
+  return basic_transmittance(rng, sf.baseLinear, sf.viewDir, sf.transmission, sf.ior, sf.outside, lightDir);
+}
 
-  p.d = (u * lightDir.x + v * lightDir.y) + ff * lightDir.z;  // :312
-  p.o = posW;                                                  // no origin offset; EPS guards self-hits
+// :306-323 once the BSDF weight and direction are known.  Returns true if the path goes on
+// to bounce+1; otherwise `sample` holds the path's radiance.
+__device__ __forceinline__ bool shade_end(Path& p, const Surface& sf, f3 weight, f3 lightDir, uint32_t bounce,
+                                          uint32_t maxBounces, f3& sample) {
+  p.mask = p.mask * weight;
+  p.d = (sf.u * lightDir.x + sf.v * lightDir.y) + sf.ff * lightDir.z;  // :312
+  p.o = sf.posW;                                                        // no origin offset; EPS guards self-hits
 
   float q = max_num(max_num(p.mask.x, p.mask.y), p.mask.z);  // :317-323
   if (q < 0.5f && bounce > kRussianRouletteBounces) {
@@ -354,6 +365,30 @@ __device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& 
     return false;
   }
   return true;
+}
+
+// UNIFIED selects the single-loop form of the three Heitz walks (heitz_bsdf_unified), which
+// keeps lanes with different lobes in step; the per-lobe functions give the same values.
+template <bool UNIFIED>
+__device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& hit, uint32_t bounce,
+                                          uint32_t maxBounces, int bsdfMode, f3& sample) {
+  Surface sf;
+  if (!shade_begin(sc, p, hit, sf, sample)) return false;
+  f3 lightDir{0.0f, 0.0f, 0.0f};
+  f3 weight;
+  if (bsdfMode != LPT_BSDF_HEITZ) {
+    weight = basic_bsdf(p.rng, sf, lightDir);
+  } else if (UNIFIED) {
+    weight = heitz_bsdf_unified(p.rng, sf.interaction, sf.baseLinear, sf.viewDir, sf.roughness, sf.ior, sf.outside,
+                                lightDir);
+  } else if (sf.interaction == kDiff) {
+    weight = diffuse_bsdf(p.rng, sf.baseLinear, sf.viewDir, sf.roughness, lightDir);
+  } else if (sf.interaction == kMetallic) {
+    weight = conductor_brdf(p.rng, sf.baseLinear, sf.viewDir, sf.roughness, lightDir);
+  } else {
+    weight = dielectric_bsdf(p.rng, sf.baseLinear, sf.viewDir, sf.roughness, sf.ior, lightDir, sf.outside);
+  }
+  return shade_end(p, sf, weight, lightDir, bounce, maxBounces, sample);
 }
 
 // ---- pixel ownership ---------------------------------------------------------------

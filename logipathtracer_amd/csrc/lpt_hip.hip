@@ -23,6 +23,7 @@
 
 #include "lpt_device.h"
 #include "lpt_extend.h"
+#include "lpt_trace.h"
 #include "lpt_internal.h"
 
 #pragma clang fp contract(off)
@@ -174,6 +175,23 @@ __global__ void k_tally(const uint32_t* __restrict__ counts, uint32_t nBounces, 
     totals[0] += counts[0];
     totals[1] += seg;
   }
+}
+
+// ---- persistent path tracer ----------------------------------------------------------
+
+// Traces every path of a batch of frames from ray generation to its radiance in `samples`
+// (lpt_trace.h).  `cursor` = kCursorRegions zeroed words.
+#ifndef LPT_TRACE_WAVES_PER_SIMD
+#define LPT_TRACE_WAVES_PER_SIMD 4
+#endif
+template <int S>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LPT_TRACE_WAVES_PER_SIMD, LPT_TRACE_WAVES_PER_SIMD)))
+void k_trace(DScene sc, Partition P, const lpt_ubo* __restrict__ ubos,
+                                                  uint32_t nFrames, uint32_t maxBounces, int bsdfMode,
+                                                  float4* __restrict__ samples, uint32_t* cursor,
+                                                  unsigned long long* totals) {
+  __shared__ TraceShared<S, kBlock> sh;
+  trace_persistent<S, kBlock>(sc, P, ubos, nFrames, maxBounces, bsdfMode, samples, cursor, totals, sh);
 }
 
 // ---- megakernel --------------------------------------------------------------------
@@ -343,6 +361,7 @@ struct lpt_ctx {
 
   // wavefront pool
   size_t poolPaths = 0;
+  int poolArrays = 0;  // float4 arrays per path in dPool: 10 (wavefront) or 1 (persistent: samples only)
   int poolBounces = 0;
   float4* dPool = nullptr;  // 2 queues x 4 arrays + hits + samples
   Queue queues[2]{};
@@ -497,31 +516,37 @@ int ensure_events(lpt_ctx* c, size_t n) {
 
 int auto_frames_in_flight(const lpt_ctx* c) {
   if (c->framesInFlight > 0) return c->framesInFlight;
-  // Every traversal launch ends with a latency-bound tail (its longest rays), whatever the
-  // number of rays, so large batches pay off: aim for 64 Mi paths in flight (about 10 GiB of
-  // queues at 160 B per path).
-  const double target = 64.0 * 1024 * 1024;
+  // Every traversal launch ends with a latency-bound tail (its longest rays, about half a
+  // millisecond whatever the number of rays), so large batches pay off: aim for 256 Mi paths in
+  // flight (about 43 GB of queues at 160 B per path; 1080p: 128 frames).  Measured on MI355X,
+  // Cornell box 1080p: 32 frames in flight 4.9, 64: 5.4, 128: 5.7 Gsamples/s.
+  const double target = 256.0 * 1024 * 1024;
   int f = (int)(target / std::max<uint32_t>(c->part.nSlots, 1u));
-  return std::min(256, std::max(1, f));
+  return std::min(2048, std::max(1, f));
 }
 
 int ensure_pool(lpt_ctx* c, int frames) {
   size_t paths = (size_t)frames * c->part.nSlots;
-  if (paths > c->poolPaths) {
+  // wavefront: 2 queues x 4 arrays + hits + samples = 10 float4 arrays; persistent: samples only
+  const int arrays = c->pipeline == LPT_PIPELINE_PERSISTENT ? 1 : 10;
+  if (paths > c->poolPaths || arrays != c->poolArrays) {
     dfree(c->dPool);
-    // 2 queues x 4 arrays + hits + samples = 10 float4 arrays
-    LPT_HIP(c, hipMalloc(&c->dPool, paths * 10 * sizeof(float4)));
+    c->poolPaths = 0;
+    LPT_HIP(c, hipMalloc(&c->dPool, paths * arrays * sizeof(float4)));
     float4* p = c->dPool;
-    for (int q = 0; q < 2; ++q) {
-      c->queues[q].o = p; p += paths;
-      c->queues[q].d = p; p += paths;
-      c->queues[q].m = p; p += paths;
-      c->queues[q].a = p; p += paths;
+    if (arrays == 10) {
+      for (int q = 0; q < 2; ++q) {
+        c->queues[q].o = p; p += paths;
+        c->queues[q].d = p; p += paths;
+        c->queues[q].m = p; p += paths;
+        c->queues[q].a = p; p += paths;
+      }
+      c->dHits = p; p += paths;
     }
-    c->dHits = p; p += paths;
     c->dSamples = p;
     LPT_HIP(c, hipMemsetAsync(c->dSamples, 0, paths * sizeof(float4), c->stream));
     c->poolPaths = paths;
+    c->poolArrays = arrays;
   }
   if (c->maxBounces + 1 > c->poolBounces) {
     dfree(c->dCounts);
@@ -609,6 +634,43 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
   hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, nB, c->dTotals);
+  LPT_HIP(c, hipGetLastError());
+  return 0;
+}
+
+template <int S>
+void launch_trace(lpt_ctx* c, int frames) {
+  // persistent grid: as many workgroups per CU as the LDS stacks allow (160 KiB per CU), at most 8
+  const size_t ldsBytes = sizeof(TraceShared<S, kBlock>);
+  int perCU = std::max<int>(1, std::min<int>(8, (int)(160 * 1024 / ldsBytes)));
+  static const int capPerCU = std::getenv("LPT_TRACE_BLOCKS_PER_CU") ? std::atoi(std::getenv("LPT_TRACE_BLOCKS_PER_CU")) : 0;
+  if (capPerCU > 0) perCU = std::min(perCU, capPerCU);
+  const size_t paths = (size_t)frames * c->part.nSlots;
+  const size_t need = (paths + kBlock - 1) / kBlock;
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
+  hipLaunchKernelGGL(k_trace<S>, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), c->part, c->dUbos,
+                     (uint32_t)frames, (uint32_t)c->maxBounces, c->bsdfMode, c->dSamples, c->dCounts, c->dTotals);
+}
+
+// A batch of frames as one persistent launch plus the frame-ordered accumulation.
+int render_batch_persistent(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
+  int rc = ensure_pool(c, frames);
+  if (rc) return rc;
+  std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
+  LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, kCursorRegions * sizeof(uint32_t), c->stream));
+  rc = ensure_events(c, c->evUsed + 2);
+  if (rc) return rc;
+  LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
+  if (c->stackNeed <= 16) launch_trace<16>(c, frames);
+  else if (c->stackNeed <= 20) launch_trace<20>(c, frames);
+  else if (c->stackNeed <= 24) launch_trace<24>(c, frames);
+  else if (c->stackNeed <= 32) launch_trace<32>(c, frames);
+  else if (c->stackNeed <= 48) launch_trace<48>(c, frames);
+  else launch_trace<64>(c, frames);
+  LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
+                     (uint32_t)frames, c->dSamples, c->dAccum);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -704,8 +766,8 @@ int lpt_create(int device, lpt_ctx** out) {
   c->stream = c->ownStream;
   if ((e = hipEventCreate(&c->evStart)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->evStop)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&c->dTotals, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMemset(c->dTotals, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipMalloc(&c->dTotals, 16 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->dTotals, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   *out = c;
   return LPT_OK;
 }
@@ -975,7 +1037,7 @@ int lpt_set_options(lpt_ctx* c, int max_bounces, int bsdf_mode, int pipeline, in
   if (!c) return LPT_ERR_INVALID;
   if (max_bounces < 1 || max_bounces > 4096) return fail(c, LPT_ERR_INVALID, "max_bounces out of range");
   if (bsdf_mode != LPT_BSDF_HEITZ && bsdf_mode != LPT_BSDF_BASIC) return fail(c, LPT_ERR_INVALID, "bad bsdf_mode");
-  if (pipeline != LPT_PIPELINE_WAVEFRONT && pipeline != LPT_PIPELINE_MEGAKERNEL)
+  if (pipeline != LPT_PIPELINE_WAVEFRONT && pipeline != LPT_PIPELINE_MEGAKERNEL && pipeline != LPT_PIPELINE_PERSISTENT)
     return fail(c, LPT_ERR_INVALID, "bad pipeline");
   if (frames_in_flight < 0 || frames_in_flight > 4096) return fail(c, LPT_ERR_INVALID, "bad frames_in_flight");
   c->maxBounces = max_bounces;
@@ -994,7 +1056,7 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   c->evUsed = 0;
   c->haveTiming = false;
-  LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, 2 * sizeof(unsigned long long), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, 16 * sizeof(unsigned long long), c->stream));
   LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
   if (c->pipeline == LPT_PIPELINE_MEGAKERNEL) {
     for (int f = 0; f < n_frames; ++f) {
@@ -1006,7 +1068,8 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     for (int f = 0; f < n_frames; f += fif) {
       int nb = std::min(fif, n_frames - f);
       if (f > 0) LPT_HIP(c, hipStreamSynchronize(c->stream));  // pinned ubo staging is reused
-      rc = render_batch_wavefront(c, ubos + f, nb);
+      rc = c->pipeline == LPT_PIPELINE_PERSISTENT ? render_batch_persistent(c, ubos + f, nb)
+                                                   : render_batch_wavefront(c, ubos + f, nb);
       if (rc) return rc;
     }
   }
@@ -1031,6 +1094,16 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   unsigned long long totals[2] = {0, 0};
   LPT_HIP(c, hipMemcpy(totals, c->dTotals, sizeof totals, hipMemcpyDeviceToHost));
+#ifdef LPT_TRACE_STATS
+  {
+    unsigned long long t[16];
+    LPT_HIP(c, hipMemcpy(t, c->dTotals, sizeof t, hipMemcpyDeviceToHost));
+    const char* names[5] = {"inner", "tri", "obj", "surface", "new"};
+    for (int k = 0; k < 5; ++k)
+      std::fprintf(stderr, "trace rounds %-8s %12llu  lanes/round %.1f\n", names[k], t[2 + 2 * k],
+                   t[2 + 2 * k] ? (double)t[3 + 2 * k] / (double)t[2 + 2 * k] : 0.0);
+  }
+#endif
   out->paths = totals[0];
   out->segments = totals[1];
   out->frames = c->lastFrames;

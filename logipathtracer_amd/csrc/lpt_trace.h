@@ -1,0 +1,351 @@
+// Persistent-thread path tracer (k_trace): whole paths stay in a lane from ray generation
+// to the final radiance, so a batch of frames is ONE launch with no ray queues in memory.
+//
+// A lane's work is cut into unit steps — one INNER node, one TRIangle, one OBJect entry of the
+// closest-hit search (exactly the sequence of intersect_scene, lpt_device.h), and the
+// "surface" steps: shade a found hit, one order of the Heitz random walk, start a new path.
+// Each round the wave runs one kind of step for the lanes that wait for it.  The search
+// kinds are picked by majority.  The surface kinds are costly and rare, so their lanes
+// wait until a fair number has gathered and then run together in one round: shade, one walk
+// order (lanes fresh from shading take their first order in the same round), the end of the
+// bounce, and a new path for every lane whose path ended.
+//
+// Per lane the arithmetic and the random numbers drawn are those of the wavefront kernels
+// (generate_ray, shade_begin, heitz_walk_step, shade_end), so the images are identical.
+#pragma once
+#include "lpt_extend.h"
+
+#pragma clang fp contract(off)
+
+namespace lpt {
+
+#ifndef LPT_SURFACE_THRESHOLD
+#define LPT_SURFACE_THRESHOLD 32
+#endif
+// Upper bound on the rounds of one wave, far above any real batch (a wave of a full-size batch
+// runs a few million): an exit every wave reaches even if a lane's state were corrupted.
+#ifndef LPT_TRACE_ROUND_LIMIT
+#define LPT_TRACE_ROUND_LIMIT (1u << 28)
+#endif
+constexpr int kTsNew = 0, kTsInner = 1, kTsTri = 2, kTsObj = 3, kTsShade = 4, kTsWalk = 5, kTsDone = 6;
+
+template <int S, int BLOCK>
+struct TraceShared {
+  uint32_t stack[S * BLOCK];
+};
+
+// `cursor` holds kCursorRegions zeroed words; `totals[0]` counts paths, `totals[1]` ray segments.
+template <int S, int BLOCK>
+__device__ __forceinline__ void trace_persistent(const DScene& sc, const Partition& P,
+                                                 const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
+                                                 uint32_t maxBounces, int bsdfMode, float4* __restrict__ samples,
+                                                 uint32_t* cursor, unsigned long long* totals,
+                                                 TraceShared<S, BLOCK>& sh) {
+  uint32_t* stk = &sh.stack[threadIdx.x];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n = nFrames * P.nSlots;  // path ids of the batch: frame-major, slot-minor
+
+  // wave-uniform chunk of path ids [chunkNext, chunkEnd)
+  uint32_t chunkNext = 0, chunkEnd = 0;
+  bool exhausted = false;
+  const uint32_t regionSize = (n + kCursorRegions - 1u) / kCursorRegions;
+  uint32_t region = blockIdx.x % kCursorRegions;
+  uint32_t regionsTried = 0;
+
+  int state = kTsNew;
+  Path p;  // p.o / p.d double as the world-space ray of the search
+  p.o = p.d = p.mask = p.acc = f3{0, 0, 0};
+  p.rng = Rng{0u, 0u};
+  uint32_t pid = 0, bounce = 0;
+  uint32_t nSegments = 0, nPaths = 0;
+
+  // A lane is either searching for a hit or sampling the BSDF at one, never both, so the two
+  // sets of per-lane variables share registers (what keeps four waves per SIMD resident):
+  //            search                         surface (state kTsWalk)
+  //   A, B, C  co, cd, cinv                   shading frame u, v, ff
+  //   D        winv                           baseLinear
+  //   E        hit (t, obj, prim)             walk energy
+  //   g0..g5   cur, sp, curObj, triI,         walk height, roughness, ior,
+  //            triEnd, inObj                  lobe | order | sides
+  //   p.o p.d  world-space ray                next origin (hit point), walk direction
+  f3 A{0, 0, 0}, B{0, 0, 0}, C{0, 0, 0}, D{0, 0, 0}, E{0, 0, 0};
+  uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0;
+
+#ifdef LPT_TRACE_STATS
+  uint32_t stRounds[5] = {0, 0, 0, 0, 0};
+  uint32_t stLanes[5] = {0, 0, 0, 0, 0};
+#define LPT_STAT(k, lanes) (++stRounds[k], stLanes[k] += (uint32_t)(lanes))
+#else
+#define LPT_STAT(k, lanes) ((void)0)
+#endif
+  for (uint32_t round = 0; round < LPT_TRACE_ROUND_LIMIT; ++round) {
+    const unsigned long long bI = __ballot(state == kTsInner);
+    const unsigned long long bT = __ballot(state == kTsTri);
+    const unsigned long long bO = __ballot(state == kTsObj);
+    const unsigned long long bSurf = __ballot(state == kTsNew || state == kTsShade || state == kTsWalk);
+    const int nI = __popcll(bI), nT = __popcll(bT), nO = __popcll(bO), nSurf = __popcll(bSurf);
+    const int busy = nI + nT + nO;
+    if (busy + nSurf == 0) break;
+
+    if (nSurf > 0 && (nSurf >= LPT_SURFACE_THRESHOLD || busy == 0)) {
+      // ---- surface round ------------------------------------------------------------
+      LPT_STAT(3, nSurf);
+      bool finish = false;  // BSDF sampled: weight / lightDir are valid
+      f3 weight{0, 0, 0}, lightDir{0, 0, 0};
+      f3 sample{0, 0, 0};
+      bool ended = false;        // path over: `sample` is its radiance
+      bool startSearch = false;  // this lane holds a new ray in p.o / p.d
+
+      // surface view of the shared registers (meaningful for lanes in kTsWalk)
+      Surface sf;
+      sf.u = A;
+      sf.v = B;
+      sf.ff = C;
+      sf.baseLinear = D;
+      sf.posW = p.o;
+      sf.viewDir = f3{0, 0, 0};
+      sf.roughness = as_float(g1);
+      sf.ior = as_float(g2);
+      sf.transmission = 0.0f;
+      sf.interaction = g3 & 7u;
+      sf.outside = (g3 >> 3) & 1u;
+      HeitzWalk walk;
+      walk.lightDir = p.d;
+      walk.energy = E;
+      walk.height = as_float(g0);
+      walk.outside = (g3 >> 4) & 1u;
+      walk.order = (int)(g3 >> 8);
+
+      if (state == kTsShade) {
+        const Hit hit{E.x, as_uint(E.y), as_uint(E.z)};
+        if (!shade_begin(sc, p, hit, sf, sample)) {
+          ended = true;
+        } else if (bsdfMode != LPT_BSDF_HEITZ) {
+          weight = basic_bsdf(p.rng, sf, lightDir);
+          finish = true;
+        } else {
+          heitz_walk_begin(walk, sf.viewDir);
+          state = kTsWalk;
+        }
+      }
+      if (state == kTsWalk && !finish && !ended) {
+        const float alpha = sf.roughness * sf.roughness;
+        const float iorOut = sf.outside ? 1.0f : sf.ior;
+        const float iorIn = sf.outside ? sf.ior : 1.0f;
+        if (heitz_walk_step(p.rng, walk, sf.interaction, sf.baseLinear, alpha, iorOut, iorIn)) {
+          weight = heitz_walk_result(walk, sf.interaction, sf.baseLinear, lightDir);
+          finish = true;
+        }
+      }
+      if (finish) {
+        if (shade_end(p, sf, weight, lightDir, bounce, maxBounces, sample)) {
+          ++bounce;
+          startSearch = true;
+        } else {
+          ended = true;
+        }
+      }
+      if (ended) {
+        samples[pid] = make_float4(sample.x, sample.y, sample.z, 0.0f);
+        state = kTsNew;
+      }
+      if (state == kTsWalk && !finish) {  // the walk goes on in a later round
+        A = sf.u;
+        B = sf.v;
+        C = sf.ff;
+        D = sf.baseLinear;
+        E = walk.energy;
+        p.o = sf.posW;
+        p.d = walk.lightDir;
+        g0 = as_uint(walk.height);
+        g1 = as_uint(sf.roughness);
+        g2 = as_uint(sf.ior);
+        g3 = sf.interaction | (sf.outside ? 8u : 0u) | (walk.outside ? 16u : 0u) | ((uint32_t)walk.order << 8);
+      }
+
+      // new paths for the lanes without one
+      const unsigned long long bN = __ballot(state == kTsNew);
+      const int nN = __popcll(bN);
+      if (nN > 0) {
+        LPT_STAT(4, nN);
+        while (!exhausted && chunkNext >= chunkEnd) {
+          const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
+          uint32_t b = 0;
+          if (lane == 0) b = atomicAdd(&cursor[region], kFetchChunk);
+          b = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
+          if (lo < hi && b < hi) {
+            chunkNext = b;
+            chunkEnd = min(b + kFetchChunk, hi);
+          } else {
+            region = (region + 1u) % kCursorRegions;
+            if (++regionsTried >= kCursorRegions) exhausted = true;
+          }
+        }
+        if (exhausted) {
+          if (state == kTsNew) state = kTsDone;
+        } else {
+          const uint32_t avail = chunkEnd - chunkNext;
+          if (state == kTsNew) {
+            const uint32_t rank =
+                __builtin_amdgcn_mbcnt_hi((uint32_t)(bN >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bN, 0u));
+            if (rank < avail) {
+              pid = chunkNext + rank;
+              const uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
+              int x, y;
+              if (slot_to_pixel(P, slot, x, y)) {
+                generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
+                bounce = 0;
+                ++nPaths;
+                startSearch = true;
+              }
+            }
+          }
+          chunkNext += min((uint32_t)nN, avail);
+        }
+      }
+
+      if (startSearch) {  // search view: a fresh closest-hit search along p.o / p.d
+        ++nSegments;
+        D = f3{1.0f / p.d.x, 1.0f / p.d.y, 1.0f / p.d.z};
+        A = p.o;
+        B = p.d;
+        C = D;
+        E = f3{kInfinity, 0.0f, 0.0f};
+        g5 = 0u;
+        stk[0] = kRefSentinel;
+        g1 = 1u;
+        g0 = sc.rootRef;
+        if (g0 == kRefSentinel) state = kTsShade;
+        else if (!(g0 & kRefLeafBit)) state = kTsInner;
+        else state = kTsObj;
+      }
+      continue;
+    }
+
+    // ---- search rounds: the kind most lanes wait for ------------------------------------
+    f3 co = A, cd = B, cinv = C;
+    const f3 winv = D;
+    Hit hit{E.x, as_uint(E.y), as_uint(E.z)};
+    uint32_t cur = g0, curObj = g2, triI = g3, triEnd = g4;
+    int sp = (int)g1;
+    bool inObj = g5 != 0u;
+    bool stepped = false;  // this lane advanced and holds a new `cur` (or needs a pop)
+    bool needPop = false;
+
+    if (nI >= nT && nI >= nO) {
+      LPT_STAT(0, nI);
+      if (state == kTsInner) {
+        const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        bool h0, h1;
+        box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+        const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+        if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+        cur = h1 ? r1 : r0;
+        needPop = !(h0 || h1);
+        stepped = true;
+      }
+    } else if (nT >= nO) {
+      LPT_STAT(1, nT);
+      if (state == kTsTri) {
+        if (triI < triEnd) {
+          const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
+          const float4 a = tq[0], b = tq[1], c = tq[2];
+          const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
+          if (td > kEps && td < hit.t) {
+            hit.t = td;
+            hit.obj = curObj;
+            hit.prim = as_uint(a.w);
+          }
+          ++triI;
+        }
+        if (triI >= triEnd) {
+          needPop = true;
+          stepped = true;
+        } else {  // stays in this leaf: keep the progress
+          E = f3{hit.t, as_float(hit.obj), as_float(hit.prim)};
+          g3 = triI;
+        }
+      }
+    } else {
+      LPT_STAT(2, nO);
+      if (state == kTsObj) {
+        const uint32_t first = leaf_first(cur);
+        const uint32_t count = leaf_count(cur);
+        if (count == 0u) {
+          needPop = true;
+        } else {
+          if (count > 1u) stk[(sp++) * BLOCK] = make_leaf_ref(first + 1u, count - 1u);
+          stk[(sp++) * BLOCK] = kRefMarker;
+          const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
+          const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
+          const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+          co = xform_point(rows, p.o);
+          cd = xform_dir(rows, p.d);
+          curObj = first;
+          inObj = true;
+          cur = as_uint(r3.x);
+          // the reciprocal direction only feeds box tests: not needed when the mesh tree is one leaf
+          if (!(cur & kRefLeafBit)) cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
+        }
+        stepped = true;
+      }
+    }
+
+    // Common tail of the search steps: take the next reference off the stack if needed and
+    // decide what the lane waits for next.  Leaving an object's mesh tree restores the
+    // world-space ray.
+    if (stepped) {
+      if (needPop) {
+        cur = stk[(--sp) * BLOCK];
+        if (cur == kRefMarker) {
+          inObj = false;
+          co = p.o;
+          cd = p.d;
+          cinv = winv;
+          cur = stk[(--sp) * BLOCK];
+        }
+      }
+      if (cur == kRefSentinel) {
+        state = kTsShade;
+      } else if (!(cur & kRefLeafBit)) {
+        state = kTsInner;
+      } else if (inObj) {
+        triI = leaf_first(cur);
+        triEnd = triI + leaf_count(cur);
+        state = kTsTri;
+      } else {
+        state = kTsObj;
+      }
+      A = co;
+      B = cd;
+      C = cinv;
+      E = f3{hit.t, as_float(hit.obj), as_float(hit.prim)};
+      g0 = cur;
+      g1 = (uint32_t)sp;
+      g2 = curObj;
+      g3 = triI;
+      g4 = triEnd;
+      g5 = inObj ? 1u : 0u;
+    }
+  }
+
+  // per-wave totals, one atomic pair per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    nSegments += (uint32_t)__shfl_down((int)nSegments, off);
+    nPaths += (uint32_t)__shfl_down((int)nPaths, off);
+  }
+  if (lane == 0 && nPaths) {
+    atomicAdd(&totals[0], (unsigned long long)nPaths);
+    atomicAdd(&totals[1], (unsigned long long)nSegments);
+  }
+#ifdef LPT_TRACE_STATS
+  if (lane == 0)
+    for (int k = 0; k < 5; ++k) {
+      atomicAdd(&totals[2 + 2 * k], (unsigned long long)stRounds[k]);
+      atomicAdd(&totals[3 + 2 * k], (unsigned long long)stLanes[k]);
+    }
+#endif
+}
+
+}  // namespace lpt

@@ -23,7 +23,7 @@ def _render_gpu(device, scene, ubos, w, h, bounces, bsdf=L.BSDF_HEITZ, pipeline=
     return img, device.stats()
 
 
-@pytest.mark.parametrize("pipeline", [L.PIPELINE_MEGAKERNEL, L.PIPELINE_WAVEFRONT])
+@pytest.mark.parametrize("pipeline", [L.PIPELINE_MEGAKERNEL, L.PIPELINE_WAVEFRONT, L.PIPELINE_PERSISTENT])
 @pytest.mark.parametrize("bounces,frames", [(2, 1), (8, 3)])
 def test_cornell_256_matches_oracle(device, cornell, cornell_oracle, pipeline, bounces, frames):
     w = h = 256
