@@ -121,10 +121,32 @@ int lpt_set_stream(lpt_ctx* ctx, void* hip_stream);
 
 /* ---- scene: bindings 2..5 of descriptor set 0 ------------------------------- */
 
+/* One GPUTexture (include/GPUTexture.hpp:9-13): the image and sampler created by
+ * PTSceneConverter::copyTextureToGPU (src/PTSceneConverter.cpp:243-389) — one mip
+ * level, RGBA8 UNORM.  Filter and address modes carry the Vulkan enum values the
+ * reference passes on (vk::Filter, vk::SamplerAddressMode). */
+typedef struct lpt_texture {
+  const void* pixels;   /* width*height*4 bytes, row 0 first */
+  uint32_t width, height;
+  uint32_t mag_filter;  /* 0 nearest, 1 linear (samplerInfo.magFilter, :356; the compute
+                           shader samples level 0, so minFilter/mipmapMode never apply) */
+  uint32_t address_u;   /* 0 repeat, 1 mirrored repeat, 2 clamp to edge, 3 clamp to border
+                           (opaque black, :363) */
+  uint32_t address_v;   /* note the reference passes wrappingW() here (:359) */
+} lpt_texture;
+#define LPT_MAX_TEXTURES 512u  /* sampler2D textures[512], shaders/path_tracing.comp:105 */
+
+/* Replaces the texture half of the scene upload: copyTextureToGPU per material texture
+ * (src/PTSceneConverter.cpp:69-84) and binding 6 of descriptor set 0
+ * (src/RendererPT.cpp:311-360).  Replaces any textures uploaded before; pixels are
+ * copied.  Call it BEFORE lpt_upload_scene: a scene is checked against the textures
+ * present at its upload, and uploading textures drops the current scene. */
+int lpt_upload_textures(lpt_ctx* ctx, const lpt_texture* textures, uint32_t n_textures);
+
 /* Replaces PTSceneConverter::copyToGPU x4 (src/PTSceneConverter.cpp:146-153) and
  * RendererPT::initializeAndBindSceneBuffer (src/RendererPT.cpp:433-509).  The
- * host arrays are copied; the caller keeps ownership.  Fails with
- * LPT_ERR_UNSUPPORTED if any object references a texture. */
+ * host arrays are copied; the caller keeps ownership.  Texture indices of the
+ * objects (0xFFFFFFFF = none) must address textures uploaded before. */
 int lpt_upload_scene(lpt_ctx* ctx, const lpt_object* objects, uint32_t n_objects,
                      const lpt_bvh_node* object_bvh, uint32_t n_object_bvh,
                      const lpt_vertex* vertices, uint32_t n_vertices,

@@ -51,6 +51,12 @@ assert OBJECT_DTYPE.itemsize == 208 and VERTEX_DTYPE.itemsize == 48
 assert NODE_DTYPE.itemsize == 48 and UBO_DTYPE.itemsize == 92
 
 
+class Texture(C.Structure):
+    """lpt_texture of include/lpt.h."""
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("mag_filter", C.c_uint32), ("address_u", C.c_uint32), ("address_v", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("frames", C.c_uint64),
                 ("device_ms", C.c_double), ("extend_ms", C.c_double),
@@ -59,7 +65,7 @@ class Stats(C.Structure):
 
 # every symbol include/lpt.h declares
 LPT_SYMBOLS = [
-    "lpt_create", "lpt_destroy", "lpt_last_error", "lpt_set_stream", "lpt_upload_scene", "lpt_resize",
+    "lpt_create", "lpt_destroy", "lpt_last_error", "lpt_set_stream", "lpt_upload_textures", "lpt_upload_scene", "lpt_resize",
     "lpt_set_partition", "lpt_set_options", "lpt_render_frames", "lpt_render_frame", "lpt_synchronize",
     "lpt_get_stats", "lpt_read_accum", "lpt_owned_slots", "lpt_owned_accum_device", "lpt_assemble_gathered",
     "lpt_resolve", "lpt_build_mesh_bvh", "lpt_debug_math", "lpt_debug_intersect",
@@ -79,6 +85,7 @@ _sig(hip, "lpt_create", _i, _i, C.POINTER(_vp))
 _sig(hip, "lpt_destroy", None, _vp)
 _sig(hip, "lpt_last_error", C.c_char_p, _vp)
 _sig(hip, "lpt_set_stream", _i, _vp, _vp)
+_sig(hip, "lpt_upload_textures", _i, _vp, _vp, _u32)
 _sig(hip, "lpt_upload_scene", _i, _vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u32)
 _sig(hip, "lpt_resize", _i, _vp, _i, _i)
 _sig(hip, "lpt_set_partition", _i, _vp, _i, _i, _i, _i)
@@ -103,6 +110,8 @@ _sig(host, "lpth_scene_counts", None, _vp, C.POINTER(_u32 * 5))
 for _n in ("lpth_scene_objects", "lpth_scene_object_bvh", "lpth_scene_vertices", "lpth_scene_mesh_bvh"):
     _sig(host, _n, _vp, _vp)
 _sig(host, "lpth_scene_camera", _i, _vp, _u32, _vp, C.POINTER(C.c_float))
+_sig(host, "lpth_scene_texture_count", _u32, _vp)
+_sig(host, "lpth_scene_texture", _vp, _vp, _u32, C.POINTER(_u32 * 5))
 _sig(host, "lpth_renderer_create", _vp, _i, _i, C.c_float, _i)
 _sig(host, "lpth_renderer_destroy", None, _vp)
 _sig(host, "lpth_renderer_load_gltf", _i, _vp, C.c_char_p, _i)

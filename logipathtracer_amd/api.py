@@ -63,6 +63,17 @@ class Scene:
             self.object_bvh = grab(N.host.lpth_scene_object_bvh, N.NODE_DTYPE, counts[1])
             self.vertices = grab(N.host.lpth_scene_vertices, N.VERTEX_DTYPE, counts[2])
             self.mesh_bvh = grab(N.host.lpth_scene_mesh_bvh, N.NODE_DTYPE, counts[3])
+            # textures in the order the object records index them: dicts with `pixels` (H,W,4) uint8,
+            # `mag_filter`, `address_u`, `address_v` (Vulkan enum values, see include/lpt.h)
+            self.textures = []
+            for i in range(N.host.lpth_scene_texture_count(h)):
+                info = (C.c_uint32 * 5)()
+                ptr = N.host.lpth_scene_texture(h, i, C.byref(info))
+                w, hgt = int(info[0]), int(info[1])
+                buf = (C.c_char * (w * hgt * 4)).from_address(ptr)
+                px = np.frombuffer(buf, dtype=np.uint8).reshape(hgt, w, 4).copy()
+                self.textures.append({"pixels": px, "mag_filter": int(info[2]), "address_u": int(info[3]),
+                                      "address_v": int(info[4])})
             self.n_cameras = int(counts[4])
             self.camera_world = None
             self.fov_y = None
@@ -76,8 +87,9 @@ class Scene:
             N.host.lpth_scene_free(h)
 
     @classmethod
-    def from_buffers(cls, objects, object_bvh, vertices, mesh_bvh, camera_world=None, fov_y=None):
+    def from_buffers(cls, objects, object_bvh, vertices, mesh_bvh, camera_world=None, fov_y=None, textures=()):
         s = cls.__new__(cls)
+        s.textures = list(textures)
         s.objects = np.ascontiguousarray(objects, dtype=N.OBJECT_DTYPE)
         s.object_bvh = np.ascontiguousarray(object_bvh, dtype=N.NODE_DTYPE)
         s.vertices = np.ascontiguousarray(vertices, dtype=N.VERTEX_DTYPE)
@@ -119,7 +131,19 @@ class Device:
     def set_stream(self, hip_stream):
         self._check(N.hip.lpt_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
+    def upload_textures(self, textures):
+        """`textures`: sequence of dicts {pixels (H,W,4) uint8, mag_filter, address_u, address_v}."""
+        keep = [np.ascontiguousarray(t["pixels"], dtype=np.uint8) for t in textures]
+        arr = (N.Texture * max(1, len(keep)))()
+        for i, (t, px) in enumerate(zip(textures, keep)):
+            if px.ndim != 3 or px.shape[2] != 4:
+                raise ValueError("texture pixels must have shape (H, W, 4)")
+            arr[i] = N.Texture(px.ctypes.data, px.shape[1], px.shape[0], int(t.get("mag_filter", 1)),
+                               int(t.get("address_u", 0)), int(t.get("address_v", 0)))
+        self._check(N.hip.lpt_upload_textures(self._ctx, C.cast(arr, C.c_void_p), len(keep)))
+
     def upload_scene(self, scene):
+        self.upload_textures(getattr(scene, "textures", ()))
         self._check(N.hip.lpt_upload_scene(
             self._ctx, _ptr(scene.objects), len(scene.objects), _ptr(scene.object_bvh), len(scene.object_bvh),
             _ptr(scene.vertices), len(scene.vertices), _ptr(scene.mesh_bvh), len(scene.mesh_bvh)))

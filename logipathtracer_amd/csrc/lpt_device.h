@@ -65,19 +65,37 @@ struct alignas(16) ObjTrav {
 };
 static_assert(sizeof(ObjTrav) == 64, "ObjTrav must be 64 bytes");
 
-// Per-object record for shading, 128 B.
+// Per-object record for shading, 160 B.  The last 32 bytes are only read for objects with
+// textures (textured != 0).
+constexpr uint32_t kNoTexture16 = 0xFFFFu;
 struct alignas(16) ObjShade {
   float inv[12];        // as in ObjTrav
   float nrm[9];         // mat3(worldMatrix) rows
-  float baseLinear[3];  // SRGBToLinear(baseColorFactor.rgb), path_tracing.comp:263
+  float baseLinear[3];  // SRGBToLinear(baseColorFactor.rgb), path_tracing.comp:263 (untextured colour)
   float emission[3];
   float roughness;      // max(roughnessFactor, 0.001), path_tracing.comp:238
   float metallic;
   float transmission;
   float ior;
-  float pad;
+  uint32_t textured;    // non-zero if any of the five texture slots is used
+  float baseFactor[4];  // baseColorFactor as uploaded (multiplied with the colour texture before SRGBToLinear)
+  uint32_t texColorEmission;         // colour | emission << 16; kNoTexture16 = slot unused
+  uint32_t texMetalRoughTransmission;  // metallicRoughness | transmission << 16
+  uint32_t texNormal;
+  uint32_t pad;
 };
-static_assert(sizeof(ObjShade) == 128, "ObjShade must be 128 bytes");
+static_assert(sizeof(ObjShade) == 160, "ObjShade must be 160 bytes");
+
+// One entry of `sampler2D textures[512]` (path_tracing.comp:105): RGBA8 image, one mip level,
+// with the sampler state src/PTSceneConverter.cpp:351-386 sets (Vulkan enum values).
+struct alignas(16) DTexture {
+  const uint8_t* pixels;  // width*height*4, row 0 first
+  uint32_t width, height;
+  uint32_t magFilter;     // 0 nearest, 1 linear
+  uint32_t addressU, addressV;  // 0 repeat, 1 mirrored repeat, 2 clamp to edge, 3 clamp to border (opaque black)
+  uint32_t pad;
+};
+static_assert(sizeof(DTexture) == 32, "DTexture must be 32 bytes");
 
 // Nodes and triangles are stored hottest first (largest world-space box first, parents
 // before children), so that a prefix of each array is what a kernel wants to keep in LDS.
@@ -87,6 +105,7 @@ struct DScene {
   const ObjTrav* otrav;
   const ObjShade* oshade;
   const lpt_vertex* verts;
+  const DTexture* textures;
   uint32_t rootRef;   // reference of the object tree's root
   uint32_t nNodes, nTris, nObjects;
 };
@@ -286,6 +305,72 @@ __device__ __forceinline__ f3 barycentric(f3 point, f3 v0, f3 v1, f3 v2) {
 // (shaders/path_tracing.comp:219-323), in two halves around the BSDF sampling so that
 // kernels may run the Heitz random walk as separately scheduled steps.
 
+// ---- texture(sampler2D, uv), path_tracing.comp:244-261,277-282 ------------------------
+// A compute shader has no derivatives, so the fetch reads mip level 0 with the sampler's
+// magnification filter.  Vulkan leaves the weight precision of linear filtering open; it is
+// fixed here: texel c -> c/255, x = u*W - 0.5, a = x - floor(x),
+// (t00*(1-a) + t10*a)*(1-b) + (t01*(1-a) + t11*a)*b.
+
+__device__ __forceinline__ int tex_floor_index(float x) {
+  float f = __builtin_floorf(x);
+  if (!(f == f)) f = 0.0f;
+  if (f < -1073741824.0f) f = -1073741824.0f;
+  if (f > 1073741824.0f) f = 1073741824.0f;
+  return (int)f;
+}
+
+// texel index, or -1 for the border colour
+__device__ __forceinline__ int tex_wrap(int i, int n, uint32_t mode) {
+  if (mode == 0u) {
+    int r = i % n;
+    return r < 0 ? r + n : r;
+  }
+  if (mode == 1u) {
+    int m = i % (2 * n);
+    if (m < 0) m += 2 * n;
+    return m < n ? m : 2 * n - 1 - m;
+  }
+  if (mode == 2u) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+  return (i < 0 || i > n - 1) ? -1 : i;
+}
+
+struct f4 {
+  float x, y, z, w;
+};
+
+__device__ __forceinline__ f4 tex_texel(const DTexture& t, int i, int j) {
+  if (i < 0 || j < 0) return f4{0.0f, 0.0f, 0.0f, 1.0f};  // eFloatOpaqueBlack
+  const uint32_t p = reinterpret_cast<const uint32_t*>(t.pixels)[(size_t)j * t.width + (size_t)i];
+  return f4{(float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f,
+            (float)(p >> 24) / 255.0f};
+}
+
+__device__ __forceinline__ f4 sample_texture(const DTexture* textures, uint32_t index, float u, float v) {
+  const DTexture t = textures[index];
+  const int W = (int)t.width, H = (int)t.height;
+  if (t.magFilter == 0u) {
+    const int i = tex_wrap(tex_floor_index(u * (float)W), W, t.addressU);
+    const int j = tex_wrap(tex_floor_index(v * (float)H), H, t.addressV);
+    return tex_texel(t, i, j);
+  }
+  const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+  float a = x - __builtin_floorf(x), b = y - __builtin_floorf(y);
+  if (!(a == a)) a = 0.0f;
+  if (!(b == b)) b = 0.0f;
+  const int i0 = tex_floor_index(x), j0 = tex_floor_index(y);
+  const int ia = tex_wrap(i0, W, t.addressU), ib = tex_wrap(i0 + 1, W, t.addressU);
+  const int ja = tex_wrap(j0, H, t.addressV), jb = tex_wrap(j0 + 1, H, t.addressV);
+  const f4 t00 = tex_texel(t, ia, ja), t10 = tex_texel(t, ib, ja), t01 = tex_texel(t, ia, jb),
+           t11 = tex_texel(t, ib, jb);
+  const float ia1 = 1.0f - a, ib1 = 1.0f - b;
+  f4 r;
+  r.x = (t00.x * ia1 + t10.x * a) * ib1 + (t01.x * ia1 + t11.x * a) * b;
+  r.y = (t00.y * ia1 + t10.y * a) * ib1 + (t01.y * ia1 + t11.y * a) * b;
+  r.z = (t00.z * ia1 + t10.z * a) * ib1 + (t01.z * ia1 + t11.z * a) * b;
+  r.w = (t00.w * ia1 + t10.w * a) * ib1 + (t01.w * ia1 + t11.w * a) * b;
+  return r;
+}
+
 // What the BSDF sampling and the rest of the iteration need from the hit surface.
 struct Surface {
   f3 u, v, ff;        // shading frame; ff = front-facing normal
@@ -313,6 +398,7 @@ __device__ __forceinline__ bool shade_begin(const DScene& sc, Path& p, const Hit
   float metallic = s7.x;
   sf.transmission = s7.y;
   sf.ior = s7.z;
+  const bool textured = as_uint(s7.w) != 0u;
 
   const float4* vq = reinterpret_cast<const float4*>(sc.verts + hit.prim);
   float4 p0 = vq[0], n0 = vq[1], p1 = vq[3], n1 = vq[4], p2 = vq[6], n2 = vq[7];
@@ -321,6 +407,34 @@ __device__ __forceinline__ bool shade_begin(const DScene& sc, Path& p, const Hit
   f3 od = xform_dir(inv, p.d);
   sf.posW = p.o + p.d * hit.t;
   f3 bary = barycentric(oo + od * hit.t, f3{p0.x, p0.y, p0.z}, f3{p1.x, p1.y, p1.z}, f3{p2.x, p2.y, p2.z});
+
+  float uvx = 0.0f, uvy = 0.0f;
+  uint32_t texNormal = kNoTexture16;
+  if (textured) {  // :234, :244-263
+    const float4 t0 = vq[2], t1 = vq[5], t2 = vq[8];
+    uvx = (bary.x * t0.x + bary.y * t1.x) + bary.z * t2.x;
+    uvy = (bary.x * t0.y + bary.y * t1.y) + bary.z * t2.y;
+    const float4 s8 = sq[8], s9 = sq[9];
+    const uint32_t ce = as_uint(s9.x), mt = as_uint(s9.y);
+    texNormal = as_uint(s9.z);
+    if ((ce & 0xFFFFu) != kNoTexture16) {
+      const f4 c = sample_texture(sc.textures, ce & 0xFFFFu, uvx, uvy);
+      sf.baseLinear = f3{srgb_to_linear(s8.x * c.x), srgb_to_linear(s8.y * c.y), srgb_to_linear(s8.z * c.z)};
+    }
+    if ((ce >> 16) != kNoTexture16) {
+      const f4 c = sample_texture(sc.textures, ce >> 16, uvx, uvy);
+      emission = emission * f3{c.x, c.y, c.z};
+    }
+    if ((mt & 0xFFFFu) != kNoTexture16) {
+      const f4 c = sample_texture(sc.textures, mt & 0xFFFFu, uvx, uvy);
+      metallic = metallic * c.z;
+      sf.roughness = sf.roughness * c.y;
+    }
+    if ((mt >> 16) != kNoTexture16) {
+      const f4 c = sample_texture(sc.textures, mt >> 16, uvx, uvy);
+      sf.transmission = sf.transmission * c.x;
+    }
+  }
 
   sf.interaction = pick_interaction(p.rng, metallic, sf.transmission);  // :266
   p.acc = p.acc + p.mask * emission;                                    // :269
@@ -331,6 +445,14 @@ __device__ __forceinline__ bool shade_begin(const DScene& sc, Path& p, const Hit
   f3 axis = (__builtin_fabsf(sf.ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
   sf.u = normalize3(cross3(axis, sf.ff));
   sf.v = cross3(sf.ff, sf.u);
+  if (textured && texNormal != kNoTexture16) {  // :277-282
+    const f4 c = sample_texture(sc.textures, texNormal, uvx, uvy);
+    const f3 tn = normalize3(f3{c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f});
+    sf.ff = normalize3((sf.u * tn.x + sf.v * tn.y) + sf.ff * tn.z);
+    axis = (__builtin_fabsf(sf.ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
+    sf.u = normalize3(cross3(axis, sf.ff));
+    sf.v = cross3(sf.ff, sf.u);
+  }
   f3 nd = -p.d;
   sf.viewDir = f3{dot3(nd, sf.u), dot3(nd, sf.v), dot3(nd, sf.ff)};
   sf.outside = dot3(normal, nd) > 0.0f;

@@ -341,6 +341,9 @@ struct lpt_ctx {
   ObjTrav* dObjTrav = nullptr;
   ObjShade* dObjShade = nullptr;
   lpt_vertex* dVerts = nullptr;
+  DTexture* dTextures = nullptr;
+  uint8_t* dTexPixels = nullptr;  // all texture images, 16-byte aligned each
+  uint32_t nTextures = 0;
   uint32_t rootRef = kRefSentinel;
   uint32_t nNodes = 0, nTris = 0, nObjects = 0;
   int stackNeed = 0;
@@ -410,6 +413,12 @@ void free_scene(lpt_ctx* c) {
   c->sceneLoaded = false;
 }
 
+void free_textures(lpt_ctx* c) {
+  dfree(c->dTextures);
+  dfree(c->dTexPixels);
+  c->nTextures = 0;
+}
+
 void free_pool(lpt_ctx* c) {
   dfree(c->dPool);
   dfree(c->dCounts);
@@ -418,7 +427,8 @@ void free_pool(lpt_ctx* c) {
 }
 
 DScene device_scene(const lpt_ctx* c) {
-  return DScene{c->dNodes, c->dTris, c->dObjTrav, c->dObjShade, c->dVerts, c->rootRef, c->nNodes, c->nTris, c->nObjects};
+  return DScene{c->dNodes,      c->dTris,   c->dObjTrav, c->dObjShade, c->dVerts,
+                c->dTextures,   c->rootRef, c->nNodes,   c->nTris,     c->nObjects};
 }
 
 // Validates the binary tree rooted at nodes[base] (child indices are offset by `base`) and
@@ -777,6 +787,7 @@ void lpt_destroy(lpt_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_scene(c);
+  free_textures(c);
   free_pool(c);
   dfree(c->dAccum);
   dfree(c->dImage);
@@ -799,6 +810,39 @@ int lpt_set_stream(lpt_ctx* c, void* hip_stream) {
   return LPT_OK;
 }
 
+int lpt_upload_textures(lpt_ctx* c, const lpt_texture* textures, uint32_t n) {
+  if (!c) return LPT_ERR_INVALID;
+  if (n > LPT_MAX_TEXTURES) return fail(c, LPT_ERR_UNSUPPORTED, "more than 512 textures");
+  if (n && !textures) return fail(c, LPT_ERR_INVALID, "null texture array");
+  std::vector<size_t> offset(n);
+  size_t total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const lpt_texture& t = textures[i];
+    if (!t.pixels || t.width == 0 || t.height == 0 || t.width > 32768u || t.height > 32768u)
+      return fail(c, LPT_ERR_INVALID, "texture without pixels or with a size outside 1..32768");
+    if (t.mag_filter > 1u || t.address_u > 3u || t.address_v > 3u)
+      return fail(c, LPT_ERR_UNSUPPORTED, "texture filter or address mode not supported");
+    offset[i] = total;
+    total += ((size_t)t.width * t.height * 4 + 15) & ~(size_t)15;
+  }
+  LPT_HIP(c, hipSetDevice(c->device));
+  LPT_HIP(c, hipStreamSynchronize(c->stream));
+  free_scene(c);  // its texture indices were checked against the old set
+  free_textures(c);
+  if (n == 0) return LPT_OK;
+  LPT_HIP(c, hipMalloc(&c->dTexPixels, total));
+  LPT_HIP(c, hipMalloc(&c->dTextures, n * sizeof(DTexture)));
+  std::vector<DTexture> desc(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const lpt_texture& t = textures[i];
+    LPT_HIP(c, hipMemcpy(c->dTexPixels + offset[i], t.pixels, (size_t)t.width * t.height * 4, hipMemcpyHostToDevice));
+    desc[i] = DTexture{c->dTexPixels + offset[i], t.width, t.height, t.mag_filter, t.address_u, t.address_v, 0u};
+  }
+  LPT_HIP(c, hipMemcpy(c->dTextures, desc.data(), n * sizeof(DTexture), hipMemcpyHostToDevice));
+  c->nTextures = n;
+  return LPT_OK;
+}
+
 int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const lpt_bvh_node* objBvh,
                      uint32_t nObjBvh, const lpt_vertex* verts, uint32_t nVerts, const lpt_bvh_node* meshBvh,
                      uint32_t nMeshBvh) {
@@ -808,9 +852,11 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
   if (nVerts % 3u != 0u) return fail(c, LPT_ERR_INVALID, "vertex count is not a multiple of 3");
   for (uint32_t i = 0; i < nObj; ++i) {
     const lpt_object& o = objects[i];
-    if ((o.colorTexture & o.emissionTexture & o.metallicRoughnessTexture & o.transmissionTexture & o.normalTexture) !=
-        0xFFFFFFFFu)
-      return fail(c, LPT_ERR_UNSUPPORTED, "textured materials are not supported");
+    const uint32_t texIds[5] = {o.colorTexture, o.emissionTexture, o.metallicRoughnessTexture, o.transmissionTexture,
+                                o.normalTexture};
+    for (uint32_t id : texIds)
+      if (id != 0xFFFFFFFFu && id >= c->nTextures)
+        return fail(c, LPT_ERR_INVALID, "object references a texture that was not uploaded (lpt_upload_textures first)");
     if (o.verticesOffset % 3u != 0u || o.verticesOffset > nVerts)
       return fail(c, LPT_ERR_INVALID, "object verticesOffset is not a triangle boundary inside the vertex buffer");
     if (o.bvhOffset >= nMeshBvh) return fail(c, LPT_ERR_INVALID, "object bvhOffset out of range");
@@ -988,6 +1034,13 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
     sh.transmission = o.transmissionFactor;
     sh.ior = o.ior;
     std::memcpy(&baseColor[4 * (size_t)i], o.baseColorFactor, 16);
+    std::memcpy(sh.baseFactor, o.baseColorFactor, 16);
+    auto id16 = [](uint32_t id) { return id == 0xFFFFFFFFu ? kNoTexture16 : id; };  // ids < LPT_MAX_TEXTURES
+    sh.texColorEmission = id16(o.colorTexture) | (id16(o.emissionTexture) << 16);
+    sh.texMetalRoughTransmission = id16(o.metallicRoughnessTexture) | (id16(o.transmissionTexture) << 16);
+    sh.texNormal = id16(o.normalTexture);
+    sh.textured = (o.colorTexture & o.emissionTexture & o.metallicRoughnessTexture & o.transmissionTexture &
+                   o.normalTexture) != 0xFFFFFFFFu;
   }
 
   free_scene(c);

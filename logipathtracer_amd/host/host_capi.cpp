@@ -84,6 +84,20 @@ const void* lpth_scene_object_bvh(void* scene) { return ((SceneHandle*)scene)->c
 const void* lpth_scene_vertices(void* scene) { return ((SceneHandle*)scene)->converter->getVerticesBuffer().data(); }
 const void* lpth_scene_mesh_bvh(void* scene) { return ((SceneHandle*)scene)->converter->getMeshBvhNodesBuffer().data(); }
 
+// Textures in the order the object records index them.  info = {width, height, magFilter,
+// addressModeU, addressModeV}; the returned pointer addresses width*height*4 RGBA8 bytes.
+uint32_t lpth_scene_texture_count(void* scene) { return (uint32_t)((SceneHandle*)scene)->converter->getTextures().size(); }
+const void* lpth_scene_texture(void* scene, uint32_t index, uint32_t info[5]) {
+  const auto& tex = ((SceneHandle*)scene)->converter->getTextures();
+  if (index >= tex.size()) return nullptr;
+  info[0] = tex[index].image->width();
+  info[1] = tex[index].image->height();
+  info[2] = tex[index].magFilter;
+  info[3] = tex[index].addressModeU;
+  info[4] = tex[index].addressModeV;
+  return tex[index].image->rawPixelData();
+}
+
 // World matrix (column-major) and vertical field of view of camera `index`.
 int lpth_scene_camera(void* scene, uint32_t index, float world_matrix[16], float* fov_y) {
   return guarded([&] {

@@ -1,4 +1,5 @@
 #include "lsg_min.hpp"
+#include "png_decode.hpp"
 
 #include <cstring>
 #include <fstream>
@@ -168,6 +169,8 @@ struct Doc {
   Value root;
   std::string dir;
   std::vector<std::string> buffers;
+  std::vector<Ref<Image>> images;      // decoded on first use
+  std::vector<Ref<Sampler>> samplers;
 };
 
 int componentCount(const std::string& type) {
@@ -230,14 +233,77 @@ void readAccessor(const Doc& d, long long index, int comps, bool asIndex, std::v
   }
 }
 
-Ref<Texture> textureRef(const Value& info) {
+std::string loadUri(const Doc& d, const std::string& uri) {
+  if (uri.compare(0, 5, "data:") == 0) {
+    size_t comma = uri.find(',');
+    if (comma == std::string::npos) throw std::runtime_error("glTF: malformed data URI");
+    return decodeBase64(uri.substr(comma + 1));
+  }
+  return readFile(d.dir + uri, true);
+}
+
+Ref<Image> loadImage(Doc& d, size_t index) {
+  const Value& images = d.root["images"];
+  if (index >= images.size()) throw std::runtime_error("glTF: image index out of range");
+  if (d.images.size() < images.size()) d.images.resize(images.size());
+  if (d.images[index]) return d.images[index];
+  const Value& ji = images[index];
+  std::string bytes;
+  auto img = makeRef<Image>();
+  if (ji.has("uri")) {
+    img->uri = ji["uri"].string();
+    bytes = loadUri(d, img->uri);
+    if (img->uri.compare(0, 5, "data:") == 0) img->uri = "data:";
+  } else if (ji.has("bufferView")) {
+    const Value& bv = d.root["bufferViews"][(size_t)ji["bufferView"].integer(-1)];
+    if (bv.isNull()) throw std::runtime_error("glTF: image bufferView out of range");
+    const size_t bi = (size_t)bv["buffer"].integer(0);
+    if (bi >= d.buffers.size()) throw std::runtime_error("glTF: buffer index out of range");
+    const size_t off = (size_t)bv["byteOffset"].integer(0), len = (size_t)bv["byteLength"].integer(0);
+    if (off + len > d.buffers[bi].size()) throw std::runtime_error("glTF: image bufferView exceeds buffer");
+    bytes = d.buffers[bi].substr(off, len);
+  } else {
+    throw std::runtime_error("glTF: image without uri or bufferView");
+  }
+  if (bytes.size() >= 3 && (unsigned char)bytes[0] == 0xFF && (unsigned char)bytes[1] == 0xD8)
+    throw std::runtime_error("glTF: JPEG texture images are not supported (convert '" + img->uri + "' to PNG)");
+  decodePNG(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), img->pixels_, img->width_, img->height_);
+  d.images[index] = img;
+  return img;
+}
+
+// glTF sampler constants -> Vulkan enum values
+uint32_t gltfFilter(long long f) { return (f == 9728 || f == 9984 || f == 9986) ? 0u : 1u; }
+uint32_t gltfWrap(long long w) { return w == 33071 ? 2u : (w == 33648 ? 1u : 0u); }
+
+Ref<Sampler> loadSampler(Doc& d, size_t index) {
+  const Value& samplers = d.root["samplers"];
+  if (index >= samplers.size()) throw std::runtime_error("glTF: sampler index out of range");
+  if (d.samplers.size() < samplers.size()) d.samplers.resize(samplers.size());
+  if (d.samplers[index]) return d.samplers[index];
+  const Value& js = samplers[index];
+  auto s = makeRef<Sampler>();
+  s->magFilter_ = gltfFilter(js["magFilter"].integer(9729));
+  s->minFilter_ = gltfFilter(js["minFilter"].integer(9729));
+  s->wrapU_ = gltfWrap(js["wrapS"].integer(10497));
+  s->wrapV_ = gltfWrap(js["wrapT"].integer(10497));
+  d.samplers[index] = s;
+  return s;
+}
+
+Ref<Texture> textureRef(Doc& d, const Value& info) {
   if (!info.isObject()) return nullptr;
-  auto t = makeRef<Texture>();  // presence is recorded; pixel data is not loaded
-  t->image_ = makeRef<Image>();
+  if (info["texCoord"].integer(0) != 0) throw std::runtime_error("glTF: only TEXCOORD_0 is supported for textures");
+  const Value& jt = d.root["textures"][(size_t)info["index"].integer(-1)];
+  if (jt.isNull()) throw std::runtime_error("glTF: texture index out of range");
+  auto t = makeRef<Texture>();
+  if (!jt.has("source")) throw std::runtime_error("glTF: texture without source image");
+  t->image_ = loadImage(d, (size_t)jt["source"].integer(-1));
+  if (jt.has("sampler")) t->sampler_ = loadSampler(d, (size_t)jt["sampler"].integer(-1));
   return t;
 }
 
-Ref<MetallicRoughnessMaterial> loadMaterial(const Value& m) {
+Ref<MetallicRoughnessMaterial> loadMaterial(Doc& d, const Value& m) {
   auto mat = makeRef<MetallicRoughnessMaterial>();
   mat->name = m["name"].string();
   const Value& pbr = m["pbrMetallicRoughness"];
@@ -248,21 +314,21 @@ Ref<MetallicRoughnessMaterial> loadMaterial(const Value& m) {
   mat->roughness_ = (float)pbr["roughnessFactor"].number(1.0);
   const Value& em = m["emissiveFactor"];
   if (em.isArray() && em.size() == 3) mat->emissive_ = {(float)em[0].number(0), (float)em[1].number(0), (float)em[2].number(0)};
-  mat->baseColorTex_ = textureRef(pbr["baseColorTexture"]);
-  mat->metallicRoughnessTex_ = textureRef(pbr["metallicRoughnessTexture"]);
-  mat->emissiveTex_ = textureRef(m["emissiveTexture"]);
-  mat->normalTex_ = textureRef(m["normalTexture"]);
+  mat->baseColorTex_ = textureRef(d, pbr["baseColorTexture"]);
+  mat->metallicRoughnessTex_ = textureRef(d, pbr["metallicRoughnessTexture"]);
+  mat->emissiveTex_ = textureRef(d, m["emissiveTexture"]);
+  mat->normalTex_ = textureRef(d, m["normalTexture"]);
   const Value& ext = m["extensions"];
   const Value& adobe = ext["ADOBE_materials_thin_transparency"];  // resources/cornell_box.gltf:269-274
   if (adobe.isObject()) {
     mat->transmission_ = (float)adobe["transmissionFactor"].number(0.0);
     mat->ior_ = (float)adobe["ior"].number(1.5);
-    mat->transmissionTex_ = textureRef(adobe["transmissionTexture"]);
+    mat->transmissionTex_ = textureRef(d, adobe["transmissionTexture"]);
   }
   const Value& khrT = ext["KHR_materials_transmission"];
   if (khrT.isObject()) {
     mat->transmission_ = (float)khrT["transmissionFactor"].number(0.0);
-    mat->transmissionTex_ = textureRef(khrT["transmissionTexture"]);
+    mat->transmissionTex_ = textureRef(d, khrT["transmissionTexture"]);
   }
   const Value& khrI = ext["KHR_materials_ior"];
   if (khrI.isObject()) mat->ior_ = (float)khrI["ior"].number(1.5);
@@ -282,6 +348,16 @@ Ref<Geometry> loadPrimitive(const Doc& d, const Value& prim) {
   if (prim.has("indices")) readAccessor(d, prim["indices"].integer(-1), 1, true, g->indices);
   for (uint32_t idx : g->indices)
     if (idx >= g->positions.size()) throw std::runtime_error("glTF: vertex index out of range");
+  if (attrs.has("TEXCOORD_0")) {
+    const Value& acc = d.root["accessors"][(size_t)attrs["TEXCOORD_0"].integer(-1)];
+    if (acc["componentType"].integer(0) == 5126) {
+      readAccessor(d, attrs["TEXCOORD_0"].integer(-1), 2, false, tmp);
+      if (tmp.size() == g->positions.size() * 2) {
+        g->uvs.resize(tmp.size() / 2);
+        for (size_t i = 0; i < g->uvs.size(); ++i) g->uvs[i] = {tmp[2 * i], tmp[2 * i + 1]};
+      }
+    }
+  }
   if (attrs.has("NORMAL")) {
     readAccessor(d, attrs["NORMAL"].integer(-1), 3, false, tmp);
     if (tmp.size() != g->positions.size() * 3) throw std::runtime_error("glTF: NORMAL count differs from POSITION count");
@@ -291,6 +367,14 @@ Ref<Geometry> loadPrimitive(const Doc& d, const Value& prim) {
     // glTF: without NORMAL, flat shading.  De-index and give every corner its face normal.
     TriangleAccessor<vec3> tri(&g->positions, &g->indices);
     std::vector<vec3> pos, nrm;
+    std::vector<vec2> uvs;
+    if (!g->uvs.empty()) {
+      TriangleAccessor<vec2> uvTri(&g->uvs, &g->indices);
+      for (size_t t = 0; t < uvTri.count(); ++t) {
+        auto T = uvTri[t];
+        uvs.push_back(T.a()); uvs.push_back(T.b()); uvs.push_back(T.c());
+      }
+    }
     for (size_t t = 0; t < tri.count(); ++t) {
       auto T = tri[t];
       vec3 n = cross(T.b() - T.a(), T.c() - T.a());
@@ -301,18 +385,9 @@ Ref<Geometry> loadPrimitive(const Doc& d, const Value& prim) {
     }
     g->positions = pos;
     g->normals = nrm;
+    g->uvs = uvs;
     g->indices.clear();
-    return g;  // TEXCOORD_0 would need the same de-indexing; dropped with the normals
-  }
-  if (attrs.has("TEXCOORD_0")) {
-    const Value& acc = d.root["accessors"][(size_t)attrs["TEXCOORD_0"].integer(-1)];
-    if (acc["componentType"].integer(0) == 5126) {
-      readAccessor(d, attrs["TEXCOORD_0"].integer(-1), 2, false, tmp);
-      if (tmp.size() == g->positions.size() * 2) {
-        g->uvs.resize(tmp.size() / 2);
-        for (size_t i = 0; i < g->uvs.size(); ++i) g->uvs[i] = {tmp[2 * i], tmp[2 * i + 1]};
-      }
-    }
+    return g;
   }
   return g;
 }
@@ -387,7 +462,7 @@ std::vector<Ref<Scene>> GLTFLoader::load(const std::string& path) {
 
   std::vector<Ref<MetallicRoughnessMaterial>> materials;
   const Value& mats = d.root["materials"];
-  for (size_t i = 0; i < mats.size(); ++i) materials.push_back(loadMaterial(mats[i]));
+  for (size_t i = 0; i < mats.size(); ++i) materials.push_back(loadMaterial(d, mats[i]));
   auto defaultMaterial = makeRef<MetallicRoughnessMaterial>();
 
   std::vector<Ref<Mesh>> meshes;

@@ -145,14 +145,41 @@ class PerspectiveCamera : public Component {
   float fov_, aspect_, near_, far_;
 };
 
+// Decoded texture image, always RGBA8 (what the reference uploads as one mip level,
+// src/PTSceneConverter.cpp:248-283).
 class Image {
  public:
+  uint32_t width() const { return width_; }
+  uint32_t height() const { return height_; }
+  size_t pixelSize() const { return 4; }
+  const void* rawPixelData() const { return pixels_.data(); }
+
   std::string uri;
+  uint32_t width_ = 0, height_ = 0;
+  std::vector<uint8_t> pixels_;  // width*height*4, row 0 first
 };
+
+// Sampler state with Vulkan enum values (vk::Filter: 0 nearest, 1 linear;
+// vk::SamplerAddressMode: 0 repeat, 1 mirrored repeat, 2 clamp to edge).  glTF only
+// describes two wrap axes; the third keeps its default.
+class Sampler {
+ public:
+  uint32_t magFilter() const { return magFilter_; }
+  uint32_t minFilter() const { return minFilter_; }
+  uint32_t wrappingU() const { return wrapU_; }
+  uint32_t wrappingV() const { return wrapV_; }
+  uint32_t wrappingW() const { return wrapW_; }
+
+  uint32_t magFilter_ = 1, minFilter_ = 1;
+  uint32_t wrapU_ = 0, wrapV_ = 0, wrapW_ = 0;
+};
+
 class Texture {
  public:
   Ref<Image> image() const { return image_; }
+  Ref<Sampler> sampler() const { return sampler_; }
   Ref<Image> image_;
+  Ref<Sampler> sampler_;  // may be null (texture without "sampler")
 };
 
 class Material {

@@ -55,9 +55,6 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
         if (verbose_) std::cout << "Unknown material. Skipping submesh." << std::endl;
         continue;
       }
-      if (material->baseColorTex() || material->emissiveTex() || material->metallicRoughnessTex() ||
-          material->transmissionTexture() || material->normalTex())
-        throw std::runtime_error("PTSceneConverter: textured materials are not supported (object '" + object->name() + "')");
 
       GPUObjectData od;
       std::memset(&od, 0, sizeof od);
@@ -72,7 +69,14 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
       od.roughnessFactor = material->roughnessFactor();
       od.transmissionFactor = material->transmissionFactor();
       od.ior = material->ior();
-      od.colorTexture = od.emissionTexture = od.metallicRoughnessTexture = od.transmissionTexture = od.normalTexture = kNoTexture;
+      // one GPU texture per material slot and object, no sharing (src/PTSceneConverter.cpp:69-84)
+      od.colorTexture = material->baseColorTex() ? copyTextureToGPU(material->baseColorTex()) : kNoTexture;
+      od.emissionTexture = material->emissiveTex() ? copyTextureToGPU(material->emissiveTex()) : kNoTexture;
+      od.metallicRoughnessTexture =
+          material->metallicRoughnessTex() ? copyTextureToGPU(material->metallicRoughnessTex()) : kNoTexture;
+      od.transmissionTexture =
+          material->transmissionTexture() ? copyTextureToGPU(material->transmissionTexture()) : kNoTexture;
+      od.normalTexture = material->normalTex() ? copyTextureToGPU(material->normalTex()) : kNoTexture;
       // element indices, not byte offsets (src/PTSceneConverter.cpp:87-88)
       od.bvhOffset = (uint32_t)meshBVHNodes_.size();
       od.verticesOffset = (uint32_t)vertices_.size();
@@ -150,11 +154,37 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
   copyToGPU();
 }
 
+// src/PTSceneConverter.cpp:243-389.  The sampler's magnification filter and address modes are
+// taken over as the reference does, including its use of wrappingW() for the V axis (:359);
+// a texture without sampler gets linear filtering and repeat (:371-376).
+uint32_t PTSceneConverter::copyTextureToGPU(const lsg::Ref<lsg::Texture>& texture) {
+  lsg::Ref<lsg::Image> image = texture->image();
+  if (!image || image->width() == 0 || image->height() == 0)
+    throw std::runtime_error("PTSceneConverter: texture without image data");
+  if (textures_.size() >= LPT_MAX_TEXTURES)
+    throw std::runtime_error("PTSceneConverter: more than 512 textures (sampler2D textures[512])");
+  GPUTexture gpuTexture;
+  gpuTexture.image = image;
+  if (lsg::Ref<lsg::Sampler> sampler = texture->sampler()) {
+    gpuTexture.magFilter = sampler->magFilter();
+    gpuTexture.addressModeU = sampler->wrappingU();
+    gpuTexture.addressModeV = sampler->wrappingW();
+  }
+  textures_.push_back(gpuTexture);
+  return (uint32_t)textures_.size() - 1u;
+}
+
 void PTSceneConverter::copyToGPU() {
   if (!device_) return;
-  int rc = lpt_upload_scene(device_, objectData_.data(), (uint32_t)objectData_.size(), objectBVHNodes_.data(),
-                            (uint32_t)objectBVHNodes_.size(), vertices_.data(), (uint32_t)vertices_.size(),
-                            meshBVHNodes_.data(), (uint32_t)meshBVHNodes_.size());
+  std::vector<lpt_texture> tex(textures_.size());
+  for (size_t i = 0; i < tex.size(); ++i)
+    tex[i] = lpt_texture{textures_[i].image->rawPixelData(), textures_[i].image->width(), textures_[i].image->height(),
+                         textures_[i].magFilter, textures_[i].addressModeU, textures_[i].addressModeV};
+  int rc = lpt_upload_textures(device_, tex.data(), (uint32_t)tex.size());
+  if (rc != LPT_OK) throw std::runtime_error(std::string("lpt_upload_textures: ") + lpt_last_error(device_));
+  rc = lpt_upload_scene(device_, objectData_.data(), (uint32_t)objectData_.size(), objectBVHNodes_.data(),
+                        (uint32_t)objectBVHNodes_.size(), vertices_.data(), (uint32_t)vertices_.size(),
+                        meshBVHNodes_.data(), (uint32_t)meshBVHNodes_.size());
   if (rc != LPT_OK) throw std::runtime_error(std::string("lpt_upload_scene: ") + lpt_last_error(device_));
 }
 
@@ -163,6 +193,7 @@ const std::vector<GPUObjectData>& PTSceneConverter::getObjectDataBuffer() const 
 const std::vector<GPUBVHNode>& PTSceneConverter::getObjectBvhNodesBuffer() const { return objectBVHNodes_; }
 const std::vector<GPUVertex>& PTSceneConverter::getVerticesBuffer() const { return vertices_; }
 const std::vector<GPUBVHNode>& PTSceneConverter::getMeshBvhNodesBuffer() const { return meshBVHNodes_; }
+const std::vector<GPUTexture>& PTSceneConverter::getTextures() const { return textures_; }
 
 void PTSceneConverter::reset() {
   cameras_.clear();
@@ -170,4 +201,5 @@ void PTSceneConverter::reset() {
   objectBVHNodes_.clear();
   vertices_.clear();
   meshBVHNodes_.clear();
+  textures_.clear();
 }

@@ -17,6 +17,14 @@ using GPUVertex = lpt_vertex;
 using GPUBVHNode = lpt_bvh_node;
 static_assert(sizeof(GPUObjectData) == 208 && sizeof(GPUVertex) == 48 && sizeof(GPUBVHNode) == 48, "scene buffer layouts");
 
+// include/GPUTexture.hpp:9-13 — image + sampler of one material texture, here as host data
+// in the form lpt_upload_textures takes.
+struct GPUTexture {
+  lsg::Ref<lsg::Image> image;
+  uint32_t magFilter = 1;                  // vk::Filter
+  uint32_t addressModeU = 0, addressModeV = 0;  // vk::SamplerAddressMode
+};
+
 class PTSceneConverter {
  public:
   // Which builder stands in for lsg::bvh::SplitBVHBuilder at src/PTSceneConverter.cpp:97-98.
@@ -37,6 +45,7 @@ class PTSceneConverter {
   const std::vector<GPUBVHNode>& getObjectBvhNodesBuffer() const;
   const std::vector<GPUVertex>& getVerticesBuffer() const;
   const std::vector<GPUBVHNode>& getMeshBvhNodesBuffer() const;
+  const std::vector<GPUTexture>& getTextures() const;
 
   void reset();
 
@@ -46,6 +55,7 @@ class PTSceneConverter {
 
  protected:
   void copyToGPU();
+  uint32_t copyTextureToGPU(const lsg::Ref<lsg::Texture>& texture);
 
  private:
   lpt_ctx* device_;
@@ -58,4 +68,5 @@ class PTSceneConverter {
   std::vector<GPUBVHNode> objectBVHNodes_;
   std::vector<GPUVertex> vertices_;
   std::vector<GPUBVHNode> meshBVHNodes_;
+  std::vector<GPUTexture> textures_;
 };

@@ -8,20 +8,81 @@ partly metallic materials, the rest diffuse with roughness 0.5-1 — from fixed-
 produces the same bytes.
 
 `write_cornell_like` is a Cornell-box-shaped scene with tunable tessellation for scaling studies.
+
+`write_textured_cornell` is the same box with every one of the five texture slots of the material model in
+use (base colour, emission, metallic-roughness, transmission, normal map), both filters and all three glTF
+wrap modes; its PNG images are written next to the .gltf by `write_png`.
 """
 import json
 import os
+import struct
+import zlib
 
 import numpy as np
 
 _SEED = 0xC0FFEE
 
 
+def write_png(path, pixels, filter_type=0):
+    """Writes an (H,W), (H,W,2), (H,W,3) or (H,W,4) uint8 array as an 8-bit PNG (grey, grey+alpha, RGB, RGBA).
+    `filter_type` 0..4 applies that PNG scan-line filter to every row (all are lossless)."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if px.ndim == 2:
+        px = px[:, :, None]
+    h, w, ch = px.shape
+    color_type = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    rows = px.reshape(h, w * ch).astype(np.int32)
+    out = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        cur = rows[y]
+        a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        b = prev
+        if filter_type == 0:
+            f = cur
+        elif filter_type == 1:
+            f = cur - a
+        elif filter_type == 2:
+            f = cur - b
+        elif filter_type == 3:
+            f = cur - ((a + b) >> 1)
+        else:
+            pa, pb, pc = np.abs(b - c), np.abs(a - c), np.abs(a + b - 2 * c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+            f = cur - pred
+        out.append(filter_type)
+        out += (f & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xFFFFFFFF)
+
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n")
+        fh.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0)))
+        fh.write(chunk(b"IDAT", zlib.compress(bytes(out), 6)))
+        fh.write(chunk(b"IEND", b""))
+
+
 class _GltfBuilder:
     def __init__(self):
         self.bin = bytearray()
         self.views, self.accessors, self.meshes, self.nodes, self.materials, self.cameras = [], [], [], [], [], []
+        self.images, self.samplers, self.textures = [], [], []
         self.scene_nodes = []
+
+    def texture(self, uri, mag=9729, wrap_s=10497, wrap_t=10497, sampler=True):
+        """Adds image `uri` (a file next to the .gltf) and a texture using it; returns the texture index.
+        glTF constants: filter 9728 nearest / 9729 linear; wrap 10497 repeat, 33648 mirrored, 33071 clamp."""
+        self.images.append({"uri": uri})
+        t = {"source": len(self.images) - 1}
+        if sampler:
+            self.samplers.append({"magFilter": mag, "minFilter": mag, "wrapS": wrap_s, "wrapT": wrap_t})
+            t["sampler"] = len(self.samplers) - 1
+        self.textures.append(t)
+        return len(self.textures) - 1
 
     def _view(self, data, target=None):
         while len(self.bin) % 4:
@@ -41,27 +102,42 @@ class _GltfBuilder:
         self.accessors.append(a)
         return len(self.accessors) - 1
 
-    def material(self, name, base=(1, 1, 1, 1), metallic=0.0, roughness=1.0, emissive=None, transmission=None, ior=None):
+    def material(self, name, base=(1, 1, 1, 1), metallic=0.0, roughness=1.0, emissive=None, transmission=None, ior=None,
+                 base_tex=None, emissive_tex=None, mr_tex=None, transmission_tex=None, normal_tex=None):
         m = {"name": name, "doubleSided": True,
              "pbrMetallicRoughness": {"baseColorFactor": [float(x) for x in base], "metallicFactor": float(metallic),
                                       "roughnessFactor": float(roughness)}}
         if emissive is not None:
             m["emissiveFactor"] = [float(x) for x in emissive]
         if transmission is not None:
-            m["extensions"] = {"ADOBE_materials_thin_transparency": {"transmissionFactor": float(transmission), "ior": float(ior)}}
+            ext = {"transmissionFactor": float(transmission), "ior": float(ior)}
+            if transmission_tex is not None:
+                ext["transmissionTexture"] = {"index": transmission_tex}
+            m["extensions"] = {"ADOBE_materials_thin_transparency": ext}
+        if base_tex is not None:
+            m["pbrMetallicRoughness"]["baseColorTexture"] = {"index": base_tex}
+        if mr_tex is not None:
+            m["pbrMetallicRoughness"]["metallicRoughnessTexture"] = {"index": mr_tex}
+        if emissive_tex is not None:
+            m["emissiveTexture"] = {"index": emissive_tex}
+        if normal_tex is not None:
+            m["normalTexture"] = {"index": normal_tex}
         self.materials.append(m)
         return len(self.materials) - 1
 
     def mesh(self, name, primitives):
-        """primitives: list of (positions (n,3), normals (n,3), indices (m,), material)"""
+        """primitives: list of (positions (n,3), normals (n,3), indices (m,), material[, uvs (n,2)])"""
         prims = []
-        for pos, nrm, idx, mat in primitives:
+        for prim in primitives:
+            pos, nrm, idx, mat = prim[:4]
             pos = np.ascontiguousarray(pos, dtype=np.float32)
             nrm = np.ascontiguousarray(nrm, dtype=np.float32)
             idx = np.ascontiguousarray(idx, dtype=np.uint32)
-            prims.append({"attributes": {"POSITION": self._accessor(pos, 5126, "VEC3", 34962, True),
-                                         "NORMAL": self._accessor(nrm, 5126, "VEC3", 34962)},
-                          "indices": self._accessor(idx, 5125, "SCALAR", 34963), "material": mat})
+            attrs = {"POSITION": self._accessor(pos, 5126, "VEC3", 34962, True),
+                     "NORMAL": self._accessor(nrm, 5126, "VEC3", 34962)}
+            if len(prim) > 4 and prim[4] is not None:
+                attrs["TEXCOORD_0"] = self._accessor(np.ascontiguousarray(prim[4], dtype=np.float32), 5126, "VEC2", 34962)
+            prims.append({"attributes": attrs, "indices": self._accessor(idx, 5125, "SCALAR", 34963), "material": mat})
         self.meshes.append({"name": name, "primitives": prims})
         return len(self.meshes) - 1
 
@@ -93,6 +169,10 @@ class _GltfBuilder:
                "materials": self.materials, "meshes": self.meshes, "accessors": self.accessors,
                "bufferViews": self.views, "buffers": [{"byteLength": len(self.bin), "uri": base + ".bin"}],
                "extensionsUsed": ["ADOBE_materials_thin_transparency"]}
+        if self.textures:
+            doc["images"], doc["textures"] = self.images, self.textures
+            if self.samplers:
+                doc["samplers"] = self.samplers
         with open(path, "w") as f:
             json.dump(doc, f)
         with open(os.path.join(os.path.dirname(path), base + ".bin"), "wb") as f:
@@ -309,3 +389,83 @@ def write_cornell_like(path, level=4):
     g.node("Camera", camera=cam, translation=(6, 1, 0), rotation=(0, s, 0, s))
     g.write(path)
     return 12 + 2 * (len(sf) // 3) + 12
+
+
+def _texture_images(rng):
+    """The six images of write_textured_cornell as uint8 arrays, keyed by file name."""
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    checker = np.where(((xx // 8 + yy // 8) % 2)[..., None] == 0, [230, 220, 200], [60, 90, 160]).astype(np.uint8)
+    gradient = np.zeros((32, 48, 4), np.uint8)  # not square, with alpha
+    gradient[..., 0] = np.linspace(40, 255, 48)[None, :]
+    gradient[..., 1] = np.linspace(255, 30, 32)[:, None]
+    gradient[..., 2] = rng.integers(0, 256, (32, 48))
+    gradient[..., 3] = 255
+    glow = np.zeros((16, 16, 3), np.uint8)
+    glow[4:12, 4:12] = [255, 240, 200]
+    glow[0:4] = [120, 20, 20]
+    mr = np.zeros((n, n, 3), np.uint8)  # g = roughness scale, b = metallic scale
+    mr[..., 1] = (40 + 200 * ((xx // 16) % 2)).astype(np.uint8)
+    mr[..., 2] = (255 * ((yy // 16) % 2)).astype(np.uint8)
+    trans = (255 * (((xx // 4) + (yy // 4)) % 2)).astype(np.uint8)  # greyscale PNG
+    ang = 2 * np.pi * xx / 16.0
+    nx, ny = 0.45 * np.sin(ang), 0.45 * np.cos(2 * np.pi * yy / 32.0)
+    nz = np.sqrt(np.maximum(0.0, 1.0 - nx * nx - ny * ny))
+    normal = np.stack([nx, ny, nz], -1)
+    normal = np.round((normal * 0.5 + 0.5) * 255).astype(np.uint8)
+    return {"tex_checker.png": checker, "tex_gradient.png": gradient, "tex_glow.png": glow, "tex_mr.png": mr,
+            "tex_trans.png": trans, "tex_normal.png": normal}
+
+
+def write_textured_cornell(path):
+    """Cornell-like box in which all five texture slots are used: checker base colour on the floor (nearest,
+    repeat, uv range 0..3), a linearly filtered RGBA gradient on the back wall (mirrored repeat / clamp,
+    uv range -0.5..1.5), an emission texture on the light, a metallic-roughness texture on the cuboid, a
+    greyscale transmission texture on a glass pane, and a normal map on the right wall (texture without
+    sampler).  Image files are written next to `path`.  Returns the number of triangles."""
+    rng = np.random.default_rng(_SEED)
+    d = os.path.dirname(path)
+    for i, (name, px) in enumerate(_texture_images(rng).items()):
+        write_png(os.path.join(d, name), px, filter_type=i % 5)
+    g = _GltfBuilder()
+    t_checker = g.texture("tex_checker.png", mag=9728, wrap_s=10497, wrap_t=10497)
+    t_gradient = g.texture("tex_gradient.png", mag=9729, wrap_s=33648, wrap_t=33071)
+    t_glow = g.texture("tex_glow.png", mag=9729, wrap_s=33071, wrap_t=33071)
+    t_mr = g.texture("tex_mr.png", mag=9728, wrap_s=10497, wrap_t=33648)
+    t_trans = g.texture("tex_trans.png", mag=9729)
+    t_normal = g.texture("tex_normal.png", sampler=False)
+    floor = g.material("Floor", (1, 1, 1, 1), 0.0, 0.4, base_tex=t_checker)
+    back = g.material("Back", (0.9, 0.9, 0.9, 1), 0.0, 0.3, base_tex=t_gradient)
+    white = g.material("White", (0.8, 0.8, 0.8, 1), 0.0, 0.11)
+    green = g.material("Green", (0.03, 0.79, 0.03, 1), 0.0, 0.3)
+    bumpy = g.material("Bumpy", (0.79, 0.2, 0.1, 1), 0.5, 0.3, normal_tex=t_normal)
+    metal = g.material("Metal", (0.9, 0.8, 0.5, 1), 1.0, 1.0, mr_tex=t_mr)
+    pane = g.material("Pane", (1, 1, 1, 1), 0.0, 0.15, transmission=1.0, ior=1.5, transmission_tex=t_trans)
+    light = g.material("Light", (1, 1, 1, 1), 0.0, 1.0, emissive=(6, 6, 6), emissive_tex=t_glow)
+    quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+    up = np.tile([0, 1, 0], (4, 1)).astype(np.float32)
+    qi = np.array([0, 2, 1, 0, 3, 2], np.uint32)
+    unit = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+
+    def plane(name, mat, uv=None):
+        return g.mesh(name, [(quad, up, qi, mat, uv)])
+
+    s = float(np.sqrt(0.5))
+    g.node("Floor", mesh=plane("FloorMesh", floor, unit * 3.0), translation=(0, 0, 0))
+    g.node("Ceiling", mesh=plane("CeilingMesh", white), translation=(0, 2, 0), rotation=(1, 0, 0, 0))
+    g.node("Back", mesh=plane("BackMesh", back, unit * 2.0 - 0.5), translation=(-1, 1, 0), rotation=(0, 0, -s, s))
+    g.node("Left", mesh=plane("LeftMesh", green), translation=(0, 1, 1), rotation=(-s, 0, 0, s))
+    g.node("Right", mesh=plane("RightMesh", bumpy, unit * 4.0), translation=(0, 1, -1), rotation=(s, 0, 0, s))
+    g.node("Light", mesh=plane("LightMesh", light, unit), translation=(0, 1.98, 0), rotation=(1, 0, 0, 0), scale=(0.5, 1, 0.5))
+    g.node("Pane", mesh=plane("PaneMesh", pane, unit * 1.5), translation=(0.3, 0.6, -0.3), rotation=(0, 0, -s, s),
+           scale=(0.45, 1, 0.45))
+    bp, bn, bi = _box()
+    buv = np.tile(unit, (len(bp) // 4, 1)).astype(np.float32) if len(bp) % 4 == 0 else np.zeros((len(bp), 2), np.float32)
+    g.node("Cuboid", mesh=g.mesh("Cuboid", [(bp, bn, bi, metal, buv)]), translation=(0.05, 0.4, 0.55), scale=(0.25, 0.4, 0.25),
+           rotation=(0, 0.3826834, 0, 0.9238795))
+    sv, sf = _icosphere(2)
+    g.node("Ball", mesh=g.mesh("Ball", [(sv, sv, sf, white)]), translation=(-0.4, 0.3, -0.2), scale=(0.3, 0.3, 0.3))
+    cam = g.camera(0.39959652)
+    g.node("Camera", camera=cam, translation=(6, 1, 0), rotation=(0, s, 0, s))
+    g.write(path)
+    return 14 + len(bi) // 3 + len(sf) // 3

@@ -23,7 +23,13 @@ class Scene(C.Structure):
     _fields_ = [("objects", C.c_void_p), ("nObjects", C.c_uint32),
                 ("objectBvh", C.c_void_p), ("nObjectBvh", C.c_uint32),
                 ("vertices", C.c_void_p), ("nVertices", C.c_uint32),
-                ("meshBvh", C.c_void_p), ("nMeshBvh", C.c_uint32)]
+                ("meshBvh", C.c_void_p), ("nMeshBvh", C.c_uint32),
+                ("textures", C.c_void_p), ("nTextures", C.c_uint32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("magFilter", C.c_uint32), ("addressU", C.c_uint32), ("addressV", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -79,6 +85,7 @@ _sig("lpto_brute_force_intersect", C.c_int, C.POINTER(Scene), _f3, _f3, _fp, C.P
 for _n in ("lpto_sin", "lpto_cos", "lpto_tan", "lpto_log", "lpto_exp"):
     _sig(_n, C.c_float, C.c_float)
 _sig("lpto_pow", C.c_float, C.c_float, C.c_float)
+_sig("lpto_sample_texture", None, C.POINTER(Texture), C.c_float, C.c_float, C.POINTER(C.c_float * 4))
 
 
 def v3(a):
@@ -88,7 +95,15 @@ def v3(a):
 class OracleScene:
     """Keeps the numpy buffers alive next to the C struct that points into them."""
 
-    def __init__(self, objects, object_bvh, vertices, mesh_bvh):
+    def __init__(self, objects, object_bvh, vertices, mesh_bvh, textures=()):
+        """`textures`: sequence of dicts {pixels: (H,W,4) uint8, mag_filter, address_u, address_v}."""
+        self.tex_pixels = [np.ascontiguousarray(t["pixels"], dtype=np.uint8) for t in textures]
+        self.tex_array = (Texture * max(1, len(textures)))()
+        for i, t in enumerate(textures):
+            px = self.tex_pixels[i]
+            assert px.ndim == 3 and px.shape[2] == 4
+            self.tex_array[i] = Texture(px.ctypes.data, px.shape[1], px.shape[0], int(t.get("mag_filter", 1)),
+                                        int(t.get("address_u", 0)), int(t.get("address_v", 0)))
         self.objects = np.ascontiguousarray(objects)
         self.object_bvh = np.ascontiguousarray(object_bvh)
         self.vertices = np.ascontiguousarray(vertices)
@@ -96,7 +111,8 @@ class OracleScene:
         assert self.objects.dtype.itemsize == 208 and self.vertices.dtype.itemsize == 48
         assert self.object_bvh.dtype.itemsize == 48 and self.mesh_bvh.dtype.itemsize == 48
         self.c = Scene(self.objects.ctypes.data, len(self.objects), self.object_bvh.ctypes.data, len(self.object_bvh),
-                       self.vertices.ctypes.data, len(self.vertices), self.mesh_bvh.ctypes.data, len(self.mesh_bvh))
+                       self.vertices.ctypes.data, len(self.vertices), self.mesh_bvh.ctypes.data, len(self.mesh_bvh),
+                       C.cast(self.tex_array, C.c_void_p).value if textures else None, len(textures))
 
 
 def render_frames(scene, ubos, width, height, max_bounces, bsdf_mode=BSDF_HEITZ, tile=None, threads=0, accum=None):
@@ -117,6 +133,14 @@ def render_frames(scene, ubos, width, height, max_bounces, bsdf_mode=BSDF_HEITZ,
         for k, v in st.as_dict().items():
             total[k] = max(total.get(k, 0), v) if k.startswith("max") else total.get(k, 0) + v
     return accum, total
+
+
+def sample_texture(pixels, u, v, mag_filter=1, address_u=0, address_v=0):
+    px = np.ascontiguousarray(pixels, dtype=np.uint8)
+    t = Texture(px.ctypes.data, px.shape[1], px.shape[0], mag_filter, address_u, address_v)
+    out = (C.c_float * 4)()
+    lib.lpto_sample_texture(C.byref(t), C.c_float(u), C.c_float(v), C.byref(out))
+    return np.array(out[:], dtype=np.float32)
 
 
 def resolve(accum, inv_sample_count):

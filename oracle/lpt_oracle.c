@@ -580,6 +580,63 @@ void lpto_bsdf(int mode, uint32_t kind, const float F0[3], const float viewDir[3
 
 typedef struct { float distance; uint32_t objectIndex; uint32_t primitiveIndex; } isect_t; /* :65-69 */
 
+/* ---- texture(sampler2D, uv), path_tracing.comp:244-261,277-282 ------------------------- */
+/* Mip level 0 (no derivatives in a compute shader), magnification filter, address modes of
+ * src/PTSceneConverter.cpp:355-360. */
+
+static inline int tex_floor_index(float x) {
+  float f = floorf(x);
+  if (!(f == f)) f = 0.0f;
+  if (f < -1073741824.0f) f = -1073741824.0f;
+  if (f > 1073741824.0f) f = 1073741824.0f;
+  return (int)f;
+}
+
+/* returns the texel index, or -1 for the border colour */
+static inline int tex_wrap(int i, int n, uint32_t mode) {
+  switch (mode) {
+    case 0u: { int r = i % n; return r < 0 ? r + n : r; }
+    case 1u: { int m = i % (2 * n); if (m < 0) m += 2 * n; return m < n ? m : 2 * n - 1 - m; }
+    case 2u: return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    default: return (i < 0 || i > n - 1) ? -1 : i;
+  }
+}
+
+static inline void tex_texel(const lpto_texture* t, int i, int j, float out[4]) {
+  if (i < 0 || j < 0) { out[0] = out[1] = out[2] = 0.0f; out[3] = 1.0f; return; } /* eFloatOpaqueBlack */
+  const uint8_t* p = t->pixels + 4u * ((size_t)j * t->width + (size_t)i);
+  for (int k = 0; k < 4; k++) out[k] = (float)p[k] / 255.0f;
+}
+
+void lpto_sample_texture(const lpto_texture* t, float u, float v, float out[4]) {
+  const int W = (int)t->width, H = (int)t->height;
+  if (t->magFilter == 0u) {
+    int i = tex_wrap(tex_floor_index(u * (float)W), W, t->addressU);
+    int j = tex_wrap(tex_floor_index(v * (float)H), H, t->addressV);
+    tex_texel(t, i, j, out);
+    return;
+  }
+  float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+  float a = x - floorf(x), b = y - floorf(y);
+  if (!(a == a)) a = 0.0f;
+  if (!(b == b)) b = 0.0f;
+  int i0 = tex_floor_index(x), j0 = tex_floor_index(y);
+  int ia = tex_wrap(i0, W, t->addressU), ib = tex_wrap(i0 + 1, W, t->addressU);
+  int ja = tex_wrap(j0, H, t->addressV), jb = tex_wrap(j0 + 1, H, t->addressV);
+  float t00[4], t10[4], t01[4], t11[4];
+  tex_texel(t, ia, ja, t00);
+  tex_texel(t, ib, ja, t10);
+  tex_texel(t, ia, jb, t01);
+  tex_texel(t, ib, jb, t11);
+  for (int k = 0; k < 4; k++) {
+    float top = t00[k] * (1.0f - a) + t10[k] * a;
+    float bot = t01[k] * (1.0f - a) + t11[k] * a;
+    out[k] = top * (1.0f - b) + bot * b;
+  }
+}
+
+#define LPT_NO_TEXTURE 0xFFFFFFFFu
+
 static inline v3 vpos(const lpto_vertex* v) { return V(v->position[0], v->position[1], v->position[2]); }
 static inline v3 vnrm(const lpto_vertex* v) { return V(v->normal[0], v->normal[1], v->normal[2]); }
 
@@ -789,7 +846,9 @@ static v3 trace_ray(const lpto_scene* sc, path_ctx* c, ray_t ray, int maxBounces
     v3 isectPositionWorld = add(ray.origin, scale(ray.direction, isect.distance));
     v3 bary = barycentric(add(rayObjOrigin, scale(rayObjDirection, isect.distance)), vpos(&vtx[0]),
                           vpos(&vtx[1]), vpos(&vtx[2]));
-    /* uv (:234) only feeds texture fetches, none of which exist without textures */
+    /* :234 */
+    float uvx = (bary.x * vtx[0].uv[0] + bary.y * vtx[1].uv[0]) + bary.z * vtx[2].uv[0];
+    float uvy = (bary.x * vtx[0].uv[1] + bary.y * vtx[1].uv[1]) + bary.z * vtx[2].uv[1];
 
     float baseColor[4] = {object->baseColorFactor[0], object->baseColorFactor[1],
                           object->baseColorFactor[2], object->baseColorFactor[3]};
@@ -798,6 +857,25 @@ static v3 trace_ray(const lpto_scene* sc, path_ctx* c, ray_t ray, int maxBounces
     float metallicFactor = object->metallicFactor;
     float transmissionFactor = object->transmissionFactor;
     float ior = object->ior;
+
+    float tx[4];
+    if (object->colorTexture != LPT_NO_TEXTURE) { /* :245-247 */
+      lpto_sample_texture(&sc->textures[object->colorTexture], uvx, uvy, tx);
+      for (int k = 0; k < 4; k++) baseColor[k] = baseColor[k] * tx[k];
+    }
+    if (object->emissionTexture != LPT_NO_TEXTURE) { /* :249-251 */
+      lpto_sample_texture(&sc->textures[object->emissionTexture], uvx, uvy, tx);
+      emissionFactor = mul(emissionFactor, V(tx[0], tx[1], tx[2]));
+    }
+    if (object->metallicRoughnessTexture != LPT_NO_TEXTURE) { /* :253-257 */
+      lpto_sample_texture(&sc->textures[object->metallicRoughnessTexture], uvx, uvy, tx);
+      metallicFactor = metallicFactor * tx[2];
+      roughnessFactor = roughnessFactor * tx[1];
+    }
+    if (object->transmissionTexture != LPT_NO_TEXTURE) { /* :259-261 */
+      lpto_sample_texture(&sc->textures[object->transmissionTexture], uvx, uvy, tx);
+      transmissionFactor = transmissionFactor * tx[0];
+    }
 
     /* :263 — SRGBToLinear(vec4); only xyz is used afterwards */
     v3 baseLinear = V(lpto_srgb_to_linear(baseColor[0]), lpto_srgb_to_linear(baseColor[1]),
@@ -813,6 +891,14 @@ static v3 trace_ray(const lpto_scene* sc, path_ctx* c, ray_t ray, int maxBounces
     v3 ffNormal = (dot(normal, ray.direction) < 0.0f) ? normal : scale(normal, -1.0f);
     v3 u = normalize(cross((fabsf(ffNormal.x) > 0.1f ? V(0.0f, 1.0f, 0.0f) : V(1.0f, 0.0f, 0.0f)), ffNormal));
     v3 v = cross(ffNormal, u);
+
+    if (object->normalTexture != LPT_NO_TEXTURE) { /* :277-282 */
+      lpto_sample_texture(&sc->textures[object->normalTexture], uvx, uvy, tx);
+      v3 tn = normalize(V(tx[0] * 2.0f - 1.0f, tx[1] * 2.0f - 1.0f, tx[2] * 2.0f - 1.0f));
+      ffNormal = normalize(add(add(scale(u, tn.x), scale(v, tn.y)), scale(ffNormal, tn.z)));
+      u = normalize(cross((fabsf(ffNormal.x) > 0.1f ? V(0.0f, 1.0f, 0.0f) : V(1.0f, 0.0f, 0.0f)), ffNormal));
+      v = cross(ffNormal, u);
+    }
 
     v3 nd = neg(ray.direction);
     v3 viewDir = V(dot(nd, u), dot(nd, v), dot(nd, ffNormal)); /* :286-288 */
@@ -850,10 +936,15 @@ int lpto_render_frame(const lpto_scene* sc, const lpto_ubo* ubo, const lpto_para
                       lpto_stats* stats) {
   for (uint32_t i = 0; i < sc->nObjects; i++) {
     const lpto_object* o = &sc->objects[i];
-    if ((o->colorTexture & o->emissionTexture & o->metallicRoughnessTexture & o->transmissionTexture &
-         o->normalTexture) != 0xFFFFFFFFu)
-      return -2; /* textures are not restated */
+    const uint32_t ids[5] = {o->colorTexture, o->emissionTexture, o->metallicRoughnessTexture,
+                             o->transmissionTexture, o->normalTexture};
+    for (int k = 0; k < 5; k++)
+      if (ids[k] != LPT_NO_TEXTURE && ids[k] >= sc->nTextures) return -2; /* texture id out of range */
   }
+  for (uint32_t i = 0; i < sc->nTextures; i++)
+    if (!sc->textures[i].pixels || sc->textures[i].width == 0 || sc->textures[i].height == 0 ||
+        sc->textures[i].width > 32768u || sc->textures[i].height > 32768u)
+      return -2;
   if (p->x0 < 0 || p->y0 < 0 || p->x0 + p->w > p->width || p->y0 + p->h > p->height) return -1;
 
   lpto_stats total;

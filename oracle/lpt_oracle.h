@@ -24,6 +24,13 @@
  *   - mat4 * (p,1) = ((c0*p.x + c1*p.y) + c2*p.z) + c3 ;  mat3 * v likewise
  *   - sin, cos, tan, log, exp, pow are the fixed polynomial algorithms in
  *     lpt_oracle.c (GLSL leaves their precision to the implementation).
+ *   - texture(sampler2D, uv) in a compute shader reads mip level 0 with the sampler's
+ *     magnification filter; Vulkan leaves the weight precision of linear filtering to
+ *     the implementation, so it is fixed here (lpto_sample_texture): RGBA8 texel c ->
+ *     c / 255, unnormalised coordinate x = u*W (nearest) or u*W - 0.5 (linear),
+ *     i0 = floor(x), a = x - floor(x), result = (t00*(1-a) + t10*a)*(1-b) + (t01*(1-a) + t11*a)*b,
+ *     texel indices wrapped per address mode.  Filtering by a real Vulkan device differs
+ *     in the last bits: "parity unpinned" for textured materials.
  */
 #ifndef LPT_ORACLE_H
 #define LPT_ORACLE_H
@@ -83,6 +90,17 @@ typedef struct {
   uint32_t reset;
 } lpto_ubo;
 
+/* One entry of `sampler2D textures[512]` (shaders/path_tracing.comp:105): the image and
+ * sampler src/PTSceneConverter.cpp:243-389 creates (one mip level, RGBA8).  Filter and
+ * address modes carry the Vulkan enum values (VkFilter, VkSamplerAddressMode). */
+typedef struct {
+  const uint8_t* pixels; /* width*height*4 bytes, row 0 first */
+  uint32_t width, height;
+  uint32_t magFilter;    /* 0 nearest, 1 linear */
+  uint32_t addressU;     /* 0 repeat, 1 mirrored repeat, 2 clamp to edge, 3 clamp to border (opaque black) */
+  uint32_t addressV;
+} lpto_texture;
+
 typedef struct {
   const lpto_object* objects;
   uint32_t nObjects;
@@ -92,6 +110,8 @@ typedef struct {
   uint32_t nVertices;
   const lpto_bvh_node* meshBvh;
   uint32_t nMeshBvh;
+  const lpto_texture* textures; /* may be NULL when nTextures == 0 */
+  uint32_t nTextures;
 } lpto_scene;
 
 enum { LPTO_BSDF_HEITZ = 0, LPTO_BSDF_BASIC = 1 };
@@ -172,6 +192,9 @@ int lpto_brute_force_intersect(const lpto_scene* scene, const float o[3], const 
 /* Analysis aid: when non-NULL, every visit of object-BVH node i / mesh-BVH node j increments
  * tlas[i] / blas[j].  Pass NULLs to switch it off (the default). */
 void lpto_set_visit_histograms(uint32_t* tlas, uint32_t* blas);
+
+/* texture(textures[i], uv) as fixed by the arithmetic contract; out = rgba. */
+void lpto_sample_texture(const lpto_texture* tex, float u, float v, float out[4]);
 
 /* The fixed transcendental algorithms of the arithmetic contract. */
 float lpto_sin(float x);

@@ -1,0 +1,195 @@
+"""Textured materials (the five texture slots of shaders/path_tracing.comp:244-261,277-282).
+
+CPU: the PNG reader of the glTF loader against PIL, the oracle's texture fetch against hand-derived
+values, the sampler hand-over of the scene converter (including the reference's use of wrappingW for the
+V axis).  GPU: parity of a scene that uses every slot, filter and wrap mode with the oracle.  Linear
+filtering follows the fixed formula of the arithmetic contract; a Vulkan device's own filtering is not
+reproduced bit for bit ("parity unpinned" for textured materials)."""
+import os
+
+import numpy as np
+import pytest
+
+import logipathtracer_amd as L
+from conftest import rel_l2
+from logipathtracer_amd import scenes
+from oracle import binding as O
+
+NEAREST, LINEAR = 0, 1
+REPEAT, MIRROR, CLAMP, BORDER = 0, 1, 2, 3
+
+
+@pytest.fixture(scope="module")
+def textured(tmp_path_factory):
+    d = tmp_path_factory.mktemp("textured")
+    path = str(d / "textured.gltf")
+    n = scenes.write_textured_cornell(path)
+    return path, n, L.Scene(path)
+
+
+def test_png_reader_matches_pil_for_all_filters_and_colour_types(textured, tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    path, _, scene = textured
+    d = os.path.dirname(path)
+    names = ["tex_checker.png", "tex_gradient.png", "tex_glow.png", "tex_mr.png", "tex_trans.png", "tex_normal.png"]
+    for name in names:  # file i was written with scan-line filter i % 5; scene.textures is in object order
+        ref = np.array(PIL.open(os.path.join(d, name)).convert("RGBA"))
+        same = [t for t in scene.textures if t["pixels"].shape == ref.shape and np.array_equal(t["pixels"], ref)]
+        assert len(same) == 1, name
+    # a palette image with transparency and a 16-bit image, written by PIL
+    rng = np.random.default_rng(3)
+    pal = PIL.fromarray(rng.integers(0, 256, (9, 7, 3), dtype=np.uint8)).convert("P", palette=PIL.ADAPTIVE, colors=17)
+    pal.save(str(tmp_path / "pal.png"), transparency=3)
+    g16 = PIL.fromarray((rng.integers(0, 65536, (5, 11)).astype(np.uint16)))
+    g16.save(str(tmp_path / "g16.png"))
+    for name in ("pal.png", "g16.png"):
+        g = scenes._GltfBuilder()
+        t = g.texture(name)
+        m = g.material("M", base_tex=t)
+        quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+        up = np.tile([0, 1, 0], (4, 1)).astype(np.float32)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+        g.node("Q", mesh=g.mesh("Q", [(quad, up, np.array([0, 2, 1, 0, 3, 2], np.uint32), m, uv)]))
+        g.node("Camera", camera=g.camera(0.5), translation=(0, 3, 0))
+        g.write(str(tmp_path / (name + ".gltf")))
+        s = L.Scene(str(tmp_path / (name + ".gltf")))
+        img = PIL.open(str(tmp_path / name))
+        if name == "g16.png":
+            ref = (np.array(img).astype(np.uint32) >> 8).astype(np.uint8)  # high byte
+            ref = np.stack([ref, ref, ref, np.full_like(ref, 255)], -1)
+        else:
+            ref = np.array(img.convert("RGBA"))
+        assert np.array_equal(s.textures[0]["pixels"], ref), name
+
+
+def test_jpeg_and_missing_images_are_rejected_with_a_message(tmp_path):
+    g = scenes._GltfBuilder()
+    m = g.material("M", base_tex=g.texture("photo.jpg"))
+    quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+    g.node("Q", mesh=g.mesh("Q", [(quad, quad * 0 + [0, 1, 0], np.array([0, 2, 1, 0, 3, 2], np.uint32), m)]))
+    g.write(str(tmp_path / "j.gltf"))
+    with pytest.raises(L.LptError, match="failed to open"):
+        L.Scene(str(tmp_path / "j.gltf"))
+    open(str(tmp_path / "photo.jpg"), "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    with pytest.raises(L.LptError, match="JPEG"):
+        L.Scene(str(tmp_path / "j.gltf"))
+
+
+def test_texture_fetch_known_answers():
+    px = np.zeros((2, 3, 4), np.uint8)  # H=2, W=3
+    px[0, 0] = [255, 0, 0, 255]
+    px[0, 1] = [0, 255, 0, 255]
+    px[0, 2] = [0, 0, 255, 255]
+    px[1, 0] = [51, 102, 153, 204]
+    px[1, 1] = [255, 255, 255, 0]
+    px[1, 2] = [10, 20, 30, 40]
+    f = np.float32
+    # nearest: texel centres and the half-open texel interval
+    assert np.array_equal(O.sample_texture(px, 0.5 / 3, 0.25, NEAREST), f([1, 0, 0, 1]))
+    assert np.array_equal(O.sample_texture(px, 1.0 / 3 + 1e-4, 0.75, NEAREST), f([1, 1, 1, 0]))
+    assert np.array_equal(O.sample_texture(px, 0.99, 0.99, NEAREST), f([10, 20, 30, 40]) / f(255))
+    # wrap modes, nearest
+    assert np.array_equal(O.sample_texture(px, 1.0 + 0.5 / 3, 0.25, NEAREST, REPEAT), f([1, 0, 0, 1]))
+    assert np.array_equal(O.sample_texture(px, -0.5 / 3, 0.25, NEAREST, REPEAT), f([0, 0, 1, 1]))
+    assert np.array_equal(O.sample_texture(px, -0.5 / 3, 0.25, NEAREST, MIRROR), f([1, 0, 0, 1]))
+    assert np.array_equal(O.sample_texture(px, 1.0 + 0.5 / 3, 0.25, NEAREST, MIRROR), f([0, 0, 1, 1]))
+    assert np.array_equal(O.sample_texture(px, 7.3, 0.25, NEAREST, CLAMP), f([0, 0, 1, 1]))
+    assert np.array_equal(O.sample_texture(px, -7.3, 0.25, NEAREST, CLAMP), f([1, 0, 0, 1]))
+    assert np.array_equal(O.sample_texture(px, 1.2, 0.25, NEAREST, BORDER), f([0, 0, 0, 1]))
+    assert np.array_equal(O.sample_texture(px, 0.2, -0.1, NEAREST, REPEAT, BORDER), f([0, 0, 0, 1]))
+    # linear: at a texel centre the texel itself, halfway between two centres their mean
+    assert np.array_equal(O.sample_texture(px, 0.5, 0.25, LINEAR, CLAMP, CLAMP), f([0, 1, 0, 1]))
+    mid = O.sample_texture(px, 1.0 / 3, 0.25, LINEAR, CLAMP, CLAMP)
+    assert np.array_equal(mid, f([0.5, 0.5, 0, 1]))
+    # the fixed formula, evaluated here in float32 step by step
+    u, v = f(0.4), f(0.6)
+    x, y = u * f(3) - f(0.5), v * f(2) - f(0.5)
+    a, b = x - np.floor(x), y - np.floor(y)
+    t = lambda i, j: px[j, i].astype(f) / f(255)
+    top = t(0, 0) * (f(1) - a) + t(1, 0) * a
+    bot = t(0, 1) * (f(1) - a) + t(1, 1) * a
+    want = top * (f(1) - b) + bot * b
+    assert np.array_equal(O.sample_texture(px, float(u), float(v), LINEAR), want.astype(f))
+    # linear + repeat wraps the second tap around the edge
+    edge = O.sample_texture(px, 0.0, 0.25, LINEAR, REPEAT, CLAMP)
+    assert np.array_equal(edge, (t(2, 0) * f(0.5) + t(0, 0) * f(0.5)).astype(f))
+    # degenerate coordinates stay defined
+    assert np.isfinite(O.sample_texture(px, float("nan"), 1e30, LINEAR)).all()
+    assert np.isfinite(O.sample_texture(px, -1e30, float("inf"), NEAREST, MIRROR, MIRROR)).all()
+
+
+def test_converter_hands_over_samplers_like_the_reference(textured):
+    _, n, scene = textured
+    assert len(scene.vertices) >= 3 * n  # spatial splits may reference a triangle from several leaves
+    tex = scene.textures
+    assert len(tex) == 6  # one GPU texture per material slot in use, in object-visit order
+    by_shape = {t["pixels"].shape[:2]: t for t in tex}
+    gradient, glow = by_shape[(32, 48)], by_shape[(16, 16)]
+    # magFilter and addressModeU come from the glTF sampler ...
+    assert (gradient["mag_filter"], gradient["address_u"]) == (LINEAR, MIRROR)
+    assert (glow["mag_filter"], glow["address_u"]) == (LINEAR, CLAMP)
+    # ... addressModeV is wrappingW() (src/PTSceneConverter.cpp:359), which glTF never sets: always repeat
+    assert all(t["address_v"] == REPEAT for t in tex)
+    # a texture without sampler: linear, repeat (src/PTSceneConverter.cpp:371-376)
+    names = ("colorTexture", "emissionTexture", "metallicRoughnessTexture", "transmissionTexture", "normalTexture")
+    used = {k: [int(i) for i in scene.objects[k] if i != 0xFFFFFFFF] for k in names}
+    assert [len(used[k]) for k in names] == [2, 1, 1, 1, 1]
+    nrm = tex[used["normalTexture"][0]]
+    assert (nrm["mag_filter"], nrm["address_u"], nrm["address_v"]) == (LINEAR, REPEAT, REPEAT)
+    assert sorted(i for k in names for i in used[k]) == list(range(6))
+    # uvs reach the vertex buffer (floor: 0..3)
+    assert float(scene.vertices["uv"].max()) == 4.0 and float(scene.vertices["uv"].min()) == -0.5
+
+
+def test_oracle_sees_the_textures(textured):
+    _, _, scene = textured
+    ubos = L.frame_ubos(scene.camera_world, scene.fov_y, 2, seed=5)
+    with_tex, st = O.render_frames(O.OracleScene(scene.objects, scene.object_bvh, scene.vertices, scene.mesh_bvh,
+                                                 scene.textures), ubos, 64, 48, 5)
+    plain = scene.objects.copy()
+    for k in ("colorTexture", "emissionTexture", "metallicRoughnessTexture", "transmissionTexture", "normalTexture"):
+        plain[k] = 0xFFFFFFFF
+    without, _ = O.render_frames(O.OracleScene(plain, scene.object_bvh, scene.vertices, scene.mesh_bvh), ubos, 64, 48, 5)
+    assert np.isfinite(with_tex).all() and rel_l2(with_tex, without) > 0.05
+    # an object that names a texture that does not exist is refused
+    bad = scene.objects.copy()
+    bad["colorTexture"][0] = 6
+    with pytest.raises(RuntimeError):
+        O.render_frames(O.OracleScene(bad, scene.object_bvh, scene.vertices, scene.mesh_bvh, scene.textures), ubos, 8, 8, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bsdf", [L.BSDF_HEITZ, L.BSDF_BASIC])
+def test_textured_scene_matches_oracle(device, textured, bsdf):
+    _, _, scene = textured
+    w, h, bounces = 256, 192, 8
+    ubos = L.frame_ubos(scene.camera_world, scene.fov_y, 3, seed=0xBEEF)
+    osc = O.OracleScene(scene.objects, scene.object_bvh, scene.vertices, scene.mesh_bvh, scene.textures)
+    ref, st = O.render_frames(osc, ubos, w, h, bounces, bsdf_mode=bsdf)
+    device.upload_scene(scene)
+    for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_MEGAKERNEL, L.PIPELINE_PERSISTENT):
+        device.resize(w, h)
+        device.set_options(bounces, bsdf, pipeline, 0)
+        device.render_frames(ubos)
+        img = device.read_accum()
+        gst = device.stats()
+        assert gst.segments == st["segments"]
+        mism = int((img[..., :3] != ref[..., :3]).any(axis=-1).sum())
+        print(f"pipeline={pipeline} rel_l2={rel_l2(img, ref):.3e} mismatching_pixels={mism}")
+        assert rel_l2(img, ref) <= 1e-4  # tolerance on pixel radiance; measured: bit-identical
+
+
+@pytest.mark.gpu
+def test_texture_upload_errors(device, textured, cornell):
+    _, _, scene = textured
+    device.upload_textures(scene.textures[:2])  # replaces the set and drops the scene
+    with pytest.raises(L.LptError, match="texture"):
+        device._check(L._native.hip.lpt_upload_scene(
+            device._ctx, scene.objects.ctypes.data, len(scene.objects), scene.object_bvh.ctypes.data,
+            len(scene.object_bvh), scene.vertices.ctypes.data, len(scene.vertices), scene.mesh_bvh.ctypes.data,
+            len(scene.mesh_bvh)))
+    with pytest.raises(L.LptError):
+        device.upload_textures([{"pixels": np.zeros((4, 4, 4), np.uint8), "mag_filter": 7}])
+    with pytest.raises(L.LptError):
+        device.upload_textures([{"pixels": np.zeros((2, 2, 4), np.uint8)}] * 513)
+    device.upload_scene(cornell)  # an untextured scene still loads afterwards
