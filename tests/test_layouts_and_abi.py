@@ -34,7 +34,7 @@ def test_vertex_node_ubo_layouts():
 
 
 def test_oracle_structs_have_the_same_sizes():
-    assert C.sizeof(O.Scene) == 64
+    assert C.sizeof(O.Scene) == 80 and C.sizeof(O.Texture) == 32
     assert C.sizeof(O.Params) == 36
 
 

@@ -117,14 +117,14 @@ def test_bvh_traversal_equals_brute_force(built):
     assert mismatches <= 2, mismatches
 
 
-def test_converter_rejects_textures_and_missing_files(tmp_path):
+def test_converter_rejects_dangling_textures_and_missing_files(tmp_path):
     import json
     g = json.load(open(CORNELL))
     g["materials"][0]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
     p = tmp_path / "tex.gltf"
     p.write_text(json.dumps(g))
     (tmp_path / "cornell_box.bin").write_bytes(open(CORNELL.replace(".gltf", ".bin"), "rb").read())
-    with pytest.raises(L.LptError, match="textured materials"):
+    with pytest.raises(L.LptError, match="texture index out of range"):  # the file declares no textures
         L.Scene(str(p))
     with pytest.raises(L.LptError, match="failed to open"):
         L.Scene(str(tmp_path / "nope.gltf"))
