@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--spp-per-step", type=int, default=128, help="frames per step and per GPU")
+    ap.add_argument("--spp-per-step", type=int, default=64, help="frames per step and per GPU")
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_box.gltf"))
@@ -231,11 +231,16 @@ def main():
             n_tri = counters["triTests"] / counters["segments"]
             bytes_per_seg = 48.0 * n_node + 36.0 * n_tri + 24.0 + 12.0
             achieved = bytes_per_seg * float(seg) / (ext_ms * 1e-3) / 1e9
+            # HBM bytes per launch: PMC measurement of this workload (profiles/extend_traffic.json holds bytes
+            # and segments per launch of the profiled run), scaled to this run's segments per launch
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
-            if os.path.exists(tpath):
+            default_workload = (os.path.basename(args.scene) == "cornell_box.gltf" and args.bounces == 8
+                                and args.pipeline == 0 and (args.width, args.height) == (1920, 1080))
+            if os.path.exists(tpath) and default_workload:
                 try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                    t = json.load(open(tpath))
+                    traffic = t["hbm_bytes_per_launch"] / t["segments_per_launch"] * float(seg) / max(ext_launches, 1)
                 except Exception:
                     traffic = None
             avg_s = ext_ms * 1e-3 / max(ext_launches, 1)

@@ -50,12 +50,19 @@ def per_dispatch(counter, kernel_substr):
 
 fetch, nf = per_dispatch("FETCH_SIZE", "k_extend")
 write, nw = per_dispatch("WRITE_SIZE", "k_extend")
+segs = None
+try:
+    b = json.load(open(os.path.join(src, "fetch.json")))
+    segs = b["traced_segments"] / b["extend_launches_rank0"]
+except Exception:
+    pass
 if fetch is not None and write is not None:
     traffic = {
         "kernel": "k_extend",
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
         "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write, "launches": nf,
         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+        "segments_per_launch": segs,
         "rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B reads as 64 B)",
     }
     json.dump(traffic, open(os.path.join(dst, "extend_traffic.json"), "w"), indent=1)
