@@ -26,6 +26,18 @@ constexpr uint32_t kCursorRegions = 8;
 #ifndef LPT_FETCH_THRESHOLD
 #define LPT_FETCH_THRESHOLD 16
 #endif
+// A burst goes on while left * DEN >= entered * NUM lanes remain in it.
+#ifndef LPT_BURST_INNER_NUM
+#define LPT_BURST_INNER_NUM 1
+#define LPT_BURST_INNER_DEN 2
+#endif
+// Triangle bursts always take the first kBurstTriFree triangles of a leaf (the builders here make
+// leaves of at most four), then apply the same kind of rule.
+#ifndef LPT_BURST_TRI_NUM
+#define LPT_BURST_TRI_NUM 1
+#define LPT_BURST_TRI_DEN 4
+#endif
+constexpr int kBurstTriFree = 4;
 constexpr int kStFetch = 0, kStInner = 1, kStTri = 2, kStObj = 3, kStDone = 4;
 
 // LDS image of one block: the traversal stacks plus the hottest prefix of the scene arrays
@@ -38,7 +50,11 @@ struct ExtendShared {
   float4 objs[KO > 0 ? KO * 4 : 1];
 };
 
-template <int S, int BLOCK, int KN, int KT, int KO>
+// BURST: a round of the INNER or TRI kind keeps going for the lanes that stay in that kind (a
+// node whose children are inner nodes, a leaf with more triangles) while at least half of
+// the lanes that entered it still do.  The burst loop carries only the reference, the stack
+// pointer and the hit, so it is much shorter than a full round of the scheduler.
+template <int S, int BLOCK, int KN, int KT, int KO, bool BURST = false>
 __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4* __restrict__ qo,
                                                   const float4* __restrict__ qd, uint32_t n,
                                                   float4* __restrict__ hits, uint32_t* cursor,
@@ -131,25 +147,61 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       }
     } else if (nI >= nT && nI >= nO) {
       if (state == kStInner) {
-        float4 q0, q1, q2, q3;
-        if (cur < hotNodes) {
-          const float4* q = &sh.nodes[cur * 4u];
-          q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+        if (BURST && KN == 0) {
+          bool mine = true;
+          for (;;) {
+            if (mine) {
+              const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+              const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+              bool h0, h1;
+              box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+              const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+              if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+              cur = h1 ? r1 : r0;
+              if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
+              mine = cur < kRefMarker;  // still an inner node (marker, leaves and the sentinel are larger)
+            }
+            const int left = __popcll(__ballot(mine));
+            if (left == 0 || LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
+          }
+          stepped = true;  // `cur` already holds the next reference
         } else {
-          const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-          q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+          float4 q0, q1, q2, q3;
+          if (cur < hotNodes) {
+            const float4* q = &sh.nodes[cur * 4u];
+            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+          } else {
+            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+          }
+          bool h0, h1;
+          box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+          const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+          if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+          cur = h1 ? r1 : r0;
+          needPop = !(h0 || h1);
+          stepped = true;
         }
-        bool h0, h1;
-        box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
-        const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-        if (h0 && h1) stk[(sp++) * BLOCK] = r0;
-        cur = h1 ? r1 : r0;
-        needPop = !(h0 || h1);
-        stepped = true;
       }
     } else if (nT >= nO) {
       if (state == kStTri) {
-        if (triI < triEnd) {
+        if (BURST && KT == 0) {
+          for (int it = 1;; ++it) {
+            if (triI < triEnd) {
+              const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
+              const float4 a = tq[0], b = tq[1], c = tq[2];
+              const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
+              if (td > kEps && td < hit.t) {
+                hit.t = td;
+                hit.obj = curObj;
+                hit.prim = as_uint(a.w);
+              }
+              ++triI;
+            }
+            const int left = __popcll(__ballot(triI < triEnd));
+            if (left == 0 || (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT)) break;
+          }
+        } else if (triI < triEnd) {
           float4 a, b, c;
           if (triI < hotTris) {
             const float4* tq = &sh.tris[triI * 3u];
@@ -204,15 +256,13 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     // Common tail: take the next reference off the stack if needed and decide what the
     // lane waits for next.  Leaving an object's mesh tree restores the world-space ray.
     if (stepped) {
-      if (needPop) {
+      if (needPop) cur = stk[(--sp) * BLOCK];
+      if (cur == kRefMarker) {  // only a pop yields the marker
+        inObj = false;
+        co = wo;
+        cd = wd;
+        cinv = winv;
         cur = stk[(--sp) * BLOCK];
-        if (cur == kRefMarker) {
-          inObj = false;
-          co = wo;
-          cd = wd;
-          cinv = winv;
-          cur = stk[(--sp) * BLOCK];
-        }
       }
       if (cur == kRefSentinel) {
         hits[rayIdx] = make_float4(hit.t, as_float(hit.obj), as_float(hit.prim), 0.0f);

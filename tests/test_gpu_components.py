@@ -217,7 +217,7 @@ def test_error_paths(device, cornell):
         dev.render_frames(L.frame_ubos(cornell.camera_world, cornell.fov_y, 1))  # nothing uploaded
     bad = L.Scene.from_buffers(cornell.objects.copy(), cornell.object_bvh, cornell.vertices, cornell.mesh_bvh)
     bad.objects["colorTexture"][0] = 0
-    with pytest.raises(L.LptError, match="textured"):
+    with pytest.raises(L.LptError, match="texture that was not uploaded"):
         dev.upload_scene(bad)
     bad = L.Scene.from_buffers(cornell.objects, cornell.object_bvh.copy(), cornell.vertices, cornell.mesh_bvh)
     inner = np.flatnonzero(bad.object_bvh["isLeaf"] == 0)
