@@ -542,7 +542,11 @@ int ensure_pool(lpt_ctx* c, int frames) {
   if (paths > c->poolPaths || arrays != c->poolArrays) {
     dfree(c->dPool);
     c->poolPaths = 0;
-    LPT_HIP(c, hipMalloc(&c->dPool, paths * arrays * sizeof(float4)));
+    if (hipMalloc(&c->dPool, paths * arrays * sizeof(float4)) != hipSuccess) {
+      (void)hipGetLastError();
+      c->dPool = nullptr;
+      return fail(c, LPT_ERR_NOMEM, "not enough device memory for " + std::to_string(frames) + " frames in flight");
+    }
     float4* p = c->dPool;
     if (arrays == 10) {
       for (int q = 0; q < 2; ++q) {
@@ -1115,7 +1119,10 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
       if (rc) return rc;
     }
   } else {
-    const int fif = auto_frames_in_flight(c);
+    // as many frames per batch as wanted and as device memory allows
+    int fif = std::min(auto_frames_in_flight(c), n_frames);
+    while ((rc = ensure_pool(c, fif)) == LPT_ERR_NOMEM && fif > 1) fif = (fif + 1) / 2;
+    if (rc) return rc;
     for (int f = 0; f < n_frames; f += fif) {
       int nb = std::min(fif, n_frames - f);
       if (f > 0) LPT_HIP(c, hipStreamSynchronize(c->stream));  // pinned ubo staging is reused

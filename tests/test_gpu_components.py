@@ -251,3 +251,19 @@ def test_full_size_properties(device, cornell):
     assert imgs[0][1].segments == imgs[1][1].segments and imgs[0][1].paths == 2 * w * h
     assert np.all(imgs[0][0][..., 3] == 2.0) and np.isfinite(imgs[0][0]).all()
     assert imgs[0][1].paths <= imgs[0][1].segments <= 8 * imgs[0][1].paths
+
+
+@pytest.mark.gpu
+def test_batch_shrinks_when_device_memory_is_short(cornell):
+    """32 frames of 8192x8192 in flight would need 344 GB of ray queues; the renderer halves the batch
+    until the pool fits and still renders every frame."""
+    dev = L.Device(0)
+    try:
+        dev.upload_scene(cornell)
+        dev.resize(8192, 8192)
+        dev.set_options(1, L.BSDF_HEITZ, L.PIPELINE_WAVEFRONT, 32)
+        dev.render_frames(L.frame_ubos(cornell.camera_world, cornell.fov_y, 32))
+        st = dev.stats()
+        assert st.paths == 32 * 8192 * 8192 and st.segments == st.paths
+    finally:
+        dev.close()
