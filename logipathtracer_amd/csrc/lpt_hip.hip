@@ -43,12 +43,16 @@ namespace {
 constexpr int kBlock = 256;
 
 // Path queue, Structure of Arrays; slot i of each array belongs to one path.
+// The radiance a path has gathered does not travel with it: it lives in samples[path id], which
+// is also where the finished path's radiance belongs.  Bit 31 of the path-id word says whether
+// that slot already holds this path's radiance (it is set by the first emissive hit); while it
+// is clear the gathered radiance is zero and the slot still holds the previous batch's data.
 struct Queue {
-  float4* o;  // origin.xyz, path id (bits)
-  float4* d;  // direction.xyz, unused
-  float4* m;  // throughput.rgb, rng.x (bits)
-  float4* a;  // gathered radiance.rgb, rng.y (bits)
+  float4* o;  // origin.xyz, path id | kAccStored (bits)
+  float4* d;  // direction.xyz, rng.x (bits)
+  float4* m;  // throughput.rgb, rng.y (bits)
 };
+constexpr uint32_t kAccStored = 0x80000000u;
 
 // Block-level append: every thread with `active` gets a distinct slot of a queue whose fill
 // count lives in *counter.  One atomic per block: a single counter word sustains only some
@@ -72,11 +76,10 @@ __device__ __forceinline__ uint32_t block_append(bool active, uint32_t* counter,
   return base + below;
 }
 
-__device__ __forceinline__ void store_path(const Queue& q, uint32_t slot, const Path& p, uint32_t pid) {
-  q.o[slot] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pid));
-  q.d[slot] = make_float4(p.d.x, p.d.y, p.d.z, 0.0f);
-  q.m[slot] = make_float4(p.mask.x, p.mask.y, p.mask.z, as_float(p.rng.x));
-  q.a[slot] = make_float4(p.acc.x, p.acc.y, p.acc.z, as_float(p.rng.y));
+__device__ __forceinline__ void store_path(const Queue& q, uint32_t slot, const Path& p, uint32_t pidWord) {
+  q.o[slot] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pidWord));
+  q.d[slot] = make_float4(p.d.x, p.d.y, p.d.z, as_float(p.rng.x));
+  q.m[slot] = make_float4(p.mask.x, p.mask.y, p.mask.z, as_float(p.rng.y));
 }
 
 // ---- wavefront kernels ---------------------------------------------------------------
@@ -130,17 +133,31 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
     Path p;
     uint32_t pid = 0;
     if (i < n) {
-      float4 o = in.o[i], d = in.d[i], m = in.m[i], a = in.a[i], h = hits[i];
+      float4 o = in.o[i], d = in.d[i], m = in.m[i], h = hits[i];
       p.o = f3{o.x, o.y, o.z};
       p.d = f3{d.x, d.y, d.z};
       p.mask = f3{m.x, m.y, m.z};
-      p.acc = f3{a.x, a.y, a.z};
-      p.rng = Rng{as_uint(m.w), as_uint(a.w)};
+      p.acc = f3{0.0f, 0.0f, 0.0f};  // shade_hit leaves this bounce's emitted radiance here (0 + mask*emission)
+      p.rng = Rng{as_uint(d.w), as_uint(m.w)};
       pid = as_uint(o.w);
+      const uint32_t slot = pid & ~kAccStored;
       Hit hit{h.x, as_uint(h.y), as_uint(h.z)};
       f3 s;
       alive = shade_hit<true>(sc, p, hit, bounce, maxBounces, bsdfMode, s);
-      if (!alive) samples[pid] = make_float4(s.x, s.y, s.z, 0.0f);
+      if (hit.t == kInfinity) {
+        samples[slot] = make_float4(s.x, s.y, s.z, 0.0f);  // mask * 0.2 replaces what was gathered
+      } else if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
+        // gathered + mask*emission, path_tracing.comp:269 (adding a zero product would change nothing)
+        f3 acc = p.acc;
+        if (pid & kAccStored) {
+          const float4 g = samples[slot];
+          acc = f3{g.x, g.y, g.z} + p.acc;
+        }
+        samples[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        pid |= kAccStored;
+      } else if (!alive && !(pid & kAccStored)) {
+        samples[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the path ends without having gathered anything
+      }
     }
     uint32_t dst = block_append(alive, countOut, lds);
     if (alive) store_path(out, dst, p, pid);
@@ -364,9 +381,9 @@ struct lpt_ctx {
 
   // wavefront pool
   size_t poolPaths = 0;
-  int poolArrays = 0;  // float4 arrays per path in dPool: 10 (wavefront) or 1 (persistent: samples only)
+  int poolArrays = 0;  // float4 arrays per path in dPool: 8 (wavefront) or 1 (persistent: samples only)
   int poolBounces = 0;
-  float4* dPool = nullptr;  // 2 queues x 4 arrays + hits + samples
+  float4* dPool = nullptr;  // 2 queues x 3 arrays + hits + samples
   Queue queues[2]{};
   float4* dHits = nullptr;
   float4* dSamples = nullptr;
@@ -528,7 +545,7 @@ int auto_frames_in_flight(const lpt_ctx* c) {
   if (c->framesInFlight > 0) return c->framesInFlight;
   // Every traversal launch ends with a latency-bound tail (its longest rays, about half a
   // millisecond whatever the number of rays), so large batches pay off: aim for 256 Mi paths in
-  // flight (about 43 GB of queues at 160 B per path; 1080p: 128 frames).  Measured on MI355X,
+  // flight (about 34 GB of queues at 128 B per path; 1080p: 128 frames).  Measured on MI355X,
   // Cornell box 1080p: 32 frames in flight 4.9, 64: 5.4, 128: 5.7 Gsamples/s.
   const double target = 256.0 * 1024 * 1024;
   int f = (int)(target / std::max<uint32_t>(c->part.nSlots, 1u));
@@ -537,8 +554,8 @@ int auto_frames_in_flight(const lpt_ctx* c) {
 
 int ensure_pool(lpt_ctx* c, int frames) {
   size_t paths = (size_t)frames * c->part.nSlots;
-  // wavefront: 2 queues x 4 arrays + hits + samples = 10 float4 arrays; persistent: samples only
-  const int arrays = c->pipeline == LPT_PIPELINE_PERSISTENT ? 1 : 10;
+  // wavefront: 2 queues x 3 arrays + hits + samples = 8 float4 arrays; persistent: samples only
+  const int arrays = c->pipeline == LPT_PIPELINE_PERSISTENT ? 1 : 8;
   if (paths > c->poolPaths || arrays != c->poolArrays) {
     dfree(c->dPool);
     c->poolPaths = 0;
@@ -548,12 +565,11 @@ int ensure_pool(lpt_ctx* c, int frames) {
       return fail(c, LPT_ERR_NOMEM, "not enough device memory for " + std::to_string(frames) + " frames in flight");
     }
     float4* p = c->dPool;
-    if (arrays == 10) {
+    if (arrays == 8) {
       for (int q = 0; q < 2; ++q) {
         c->queues[q].o = p; p += paths;
         c->queues[q].d = p; p += paths;
         c->queues[q].m = p; p += paths;
-        c->queues[q].a = p; p += paths;
       }
       c->dHits = p; p += paths;
     }
@@ -1121,6 +1137,8 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   } else {
     // as many frames per batch as wanted and as device memory allows
     int fif = std::min(auto_frames_in_flight(c), n_frames);
+    // path ids of a batch must leave bit 31 free (kAccStored)
+    fif = std::max(1, std::min<int>(fif, (int)(0x7FFFFFFFu / std::max<uint32_t>(c->part.nSlots, 1u))));
     while ((rc = ensure_pool(c, fif)) == LPT_ERR_NOMEM && fif > 1) fif = (fif + 1) / 2;
     if (rc) return rc;
     for (int f = 0; f < n_frames; f += fif) {
