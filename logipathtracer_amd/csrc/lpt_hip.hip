@@ -76,6 +76,25 @@ __device__ __forceinline__ uint32_t block_append(bool active, uint32_t* counter,
   return base + below;
 }
 
+// Rank of this thread among the block's `active` threads (thread order) and their number.
+// Must be called by all threads of the block.
+__device__ __forceinline__ uint32_t block_rank(bool active, uint32_t* lds /* [kBlock/64 + 1] */, uint32_t& total) {
+  const unsigned long long ballot = __ballot(active);
+  const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+  const uint32_t wave = threadIdx.x >> 6;
+  __syncthreads();  // the previous user's readers are done with lds
+  if ((threadIdx.x & 63u) == 0u) lds[wave] = (uint32_t)__popcll(ballot);
+  __syncthreads();
+  uint32_t base = 0;
+  total = 0;
+  for (uint32_t w = 0; w < kBlock / 64; ++w) {
+    const uint32_t c = lds[w];
+    if (w < wave) base += c;
+    total += c;
+  }
+  return base + below;
+}
+
 __device__ __forceinline__ void store_path(const Queue& q, uint32_t slot, const Path& p, uint32_t pidWord) {
   q.o[slot] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pidWord));
   q.d[slot] = make_float4(p.d.x, p.d.y, p.d.z, as_float(p.rng.x));
@@ -119,48 +138,88 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, const float4* __res
   extend_persistent<S, BLOCK, KN, KT, KO, BURST>(sc, qo, qd, *count, hits, cursor, sh);
 }
 
-// Shades every queued hit, samples the next direction, applies Russian roulette; paths
-// that go on are appended to `out`, finished paths write their radiance to `samples[pid]`.
+// Shades queue entry i (a ray that hit something), samples the next direction, applies Russian
+// roulette.  Returns true if the path goes on (p, pidWord are what to queue); the radiance of a
+// finished path is in samples[path id].
+__device__ __forceinline__ bool shade_entry(const DScene& sc, const Queue& in, const float4* __restrict__ hits,
+                                            uint32_t i, float4* __restrict__ samples, uint32_t bounce,
+                                            uint32_t maxBounces, int bsdfMode, Path& p, uint32_t& pidWord) {
+  const float4 o = in.o[i], d = in.d[i], m = in.m[i], h = hits[i];
+  p.o = f3{o.x, o.y, o.z};
+  p.d = f3{d.x, d.y, d.z};
+  p.mask = f3{m.x, m.y, m.z};
+  p.acc = f3{0.0f, 0.0f, 0.0f};  // shade_hit leaves this bounce's emitted radiance here (0 + mask*emission)
+  p.rng = Rng{as_uint(d.w), as_uint(m.w)};
+  pidWord = as_uint(o.w);
+  const uint32_t slot = pidWord & ~kAccStored;
+  const Hit hit{h.x, as_uint(h.y), as_uint(h.z)};
+  f3 s;
+  const bool alive = shade_hit<true>(sc, p, hit, bounce, maxBounces, bsdfMode, s);
+  if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
+    // gathered + mask*emission, path_tracing.comp:269 (adding a zero product would change nothing)
+    f3 acc = p.acc;
+    if (pidWord & kAccStored) {
+      const float4 g = samples[slot];
+      acc = f3{g.x, g.y, g.z} + p.acc;
+    }
+    samples[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    pidWord |= kAccStored;
+  } else if (!alive && !(pidWord & kAccStored)) {
+    samples[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the path ends without having gathered anything
+  }
+  return alive;
+}
+
+// One bounce of shading for the whole queue.  Rays that missed (a quarter of them in an open
+// scene) are finished while the queue is scanned; the indices of the hits collect in LDS and
+// are shaded 256 at a time, so the expensive part always runs with full waves.  Paths that go
+// on are appended to `out`.
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const float4* __restrict__ hits,
                                                   const uint32_t* __restrict__ countIn, Queue out, uint32_t* countOut,
                                                   float4* __restrict__ samples, uint32_t bounce, uint32_t maxBounces,
                                                   int bsdfMode) {
   __shared__ uint32_t lds[kBlock / 64 + 1];
+  __shared__ uint32_t pending[2 * kBlock];  // indices of hits not shaded yet; fewer than kBlock between scans
   const uint32_t n = *countIn;
+  uint32_t nPending = 0;  // same value in every thread of the block
   for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-    uint32_t i = base + threadIdx.x;
-    bool alive = false;
-    Path p;
-    uint32_t pid = 0;
+    const uint32_t i = base + threadIdx.x;
+    bool isHit = false;
     if (i < n) {
-      float4 o = in.o[i], d = in.d[i], m = in.m[i], h = hits[i];
-      p.o = f3{o.x, o.y, o.z};
-      p.d = f3{d.x, d.y, d.z};
-      p.mask = f3{m.x, m.y, m.z};
-      p.acc = f3{0.0f, 0.0f, 0.0f};  // shade_hit leaves this bounce's emitted radiance here (0 + mask*emission)
-      p.rng = Rng{as_uint(d.w), as_uint(m.w)};
-      pid = as_uint(o.w);
-      const uint32_t slot = pid & ~kAccStored;
-      Hit hit{h.x, as_uint(h.y), as_uint(h.z)};
-      f3 s;
-      alive = shade_hit<true>(sc, p, hit, bounce, maxBounces, bsdfMode, s);
-      if (hit.t == kInfinity) {
-        samples[slot] = make_float4(s.x, s.y, s.z, 0.0f);  // mask * 0.2 replaces what was gathered
-      } else if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
-        // gathered + mask*emission, path_tracing.comp:269 (adding a zero product would change nothing)
-        f3 acc = p.acc;
-        if (pid & kAccStored) {
-          const float4 g = samples[slot];
-          acc = f3{g.x, g.y, g.z} + p.acc;
-        }
-        samples[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-        pid |= kAccStored;
-      } else if (!alive && !(pid & kAccStored)) {
-        samples[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the path ends without having gathered anything
+      if (hits[i].x == kInfinity) {  // path_tracing.comp:220-223 — assignment: radiance gathered so far is dropped
+        const float4 m = in.m[i];
+        const f3 s = f3{m.x, m.y, m.z} * 0.2f;
+        samples[as_uint(in.o[i].w) & ~kAccStored] = make_float4(s.x, s.y, s.z, 0.0f);
+      } else {
+        isHit = true;
       }
     }
-    uint32_t dst = block_append(alive, countOut, lds);
-    if (alive) store_path(out, dst, p, pid);
+    uint32_t nHits;
+    const uint32_t rank = block_rank(isHit, lds, nHits);
+    if (isHit) pending[nPending + rank] = i;
+    nPending += nHits;
+    __syncthreads();
+    if (nPending >= (uint32_t)kBlock) {
+      Path p;
+      uint32_t pidWord;
+      const bool alive = shade_entry(sc, in, hits, pending[threadIdx.x], samples, bounce, maxBounces, bsdfMode, p, pidWord);
+      const uint32_t carry = threadIdx.x + kBlock < nPending ? pending[threadIdx.x + kBlock] : 0u;
+      const uint32_t dst = block_append(alive, countOut, lds);  // synchronises the block
+      if (alive) store_path(out, dst, p, pidWord);
+      nPending -= kBlock;
+      if (threadIdx.x < nPending) pending[threadIdx.x] = carry;
+      // the next writer of pending[] comes after block_rank's barriers
+    }
+  }
+  if (nPending > 0) {
+    __syncthreads();
+    bool alive = false;
+    Path p;
+    uint32_t pidWord = 0;
+    if (threadIdx.x < nPending)
+      alive = shade_entry(sc, in, hits, pending[threadIdx.x], samples, bounce, maxBounces, bsdfMode, p, pidWord);
+    const uint32_t dst = block_append(alive, countOut, lds);
+    if (alive) store_path(out, dst, p, pidWord);
   }
 }
 
