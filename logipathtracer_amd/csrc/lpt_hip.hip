@@ -76,25 +76,6 @@ __device__ __forceinline__ uint32_t block_append(bool active, uint32_t* counter,
   return base + below;
 }
 
-// Rank of this thread among the block's `active` threads (thread order) and their number.
-// Must be called by all threads of the block.
-__device__ __forceinline__ uint32_t block_rank(bool active, uint32_t* lds /* [kBlock/64 + 1] */, uint32_t& total) {
-  const unsigned long long ballot = __ballot(active);
-  const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-  const uint32_t wave = threadIdx.x >> 6;
-  __syncthreads();  // the previous user's readers are done with lds
-  if ((threadIdx.x & 63u) == 0u) lds[wave] = (uint32_t)__popcll(ballot);
-  __syncthreads();
-  uint32_t base = 0;
-  total = 0;
-  for (uint32_t w = 0; w < kBlock / 64; ++w) {
-    const uint32_t c = lds[w];
-    if (w < wave) base += c;
-    total += c;
-  }
-  return base + below;
-}
-
 __device__ __forceinline__ void store_path(const Queue& q, uint32_t slot, const Path& p, uint32_t pidWord) {
   q.o[slot] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pidWord));
   q.d[slot] = make_float4(p.d.x, p.d.y, p.d.z, as_float(p.rng.x));
@@ -170,57 +151,86 @@ __device__ __forceinline__ bool shade_entry(const DScene& sc, const Queue& in, c
   return alive;
 }
 
-// One bounce of shading for the whole queue.  Rays that missed (a quarter of them in an open
-// scene) are finished while the queue is scanned; the indices of the hits collect in LDS and
-// are shaded 256 at a time, so the expensive part always runs with full waves.  Paths that go
-// on are appended to `out`.
+// The lobe a hit on this object will most likely sample (0 diffuse, 1 conductor, 2 dielectric):
+// the largest of the weights of heitz/interaction_type.glsl:12-14.
+__device__ __forceinline__ uint32_t likely_lobe(const ObjShade& os) {
+  const float wm = os.metallic, wt = (1.0f - os.metallic) * os.transmission;
+  const float wd = (1.0f - os.transmission) * (1.0f - os.metallic);
+  return (wm >= wt && wm >= wd) ? 1u : (wt >= wd ? 2u : 0u);
+}
+
+constexpr int kShadeClasses = 3;
+
+// One bounce of shading for the whole queue.  Rays that missed are finished while the queue is
+// scanned; the indices of the hits collect in LDS, one list per likely lobe, and a list is
+// shaded when it holds a full block, so the expensive part runs with full waves whose lanes
+// mostly take the same branches.  The order in which paths are shaded does not matter: every
+// path owns its random-number state.  Paths that go on are appended to `out`.
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const float4* __restrict__ hits,
                                                   const uint32_t* __restrict__ countIn, Queue out, uint32_t* countOut,
                                                   float4* __restrict__ samples, uint32_t bounce, uint32_t maxBounces,
                                                   int bsdfMode) {
   __shared__ uint32_t lds[kBlock / 64 + 1];
-  __shared__ uint32_t pending[2 * kBlock];  // indices of hits not shaded yet; fewer than kBlock between scans
+  __shared__ uint32_t waveCount[kShadeClasses][kBlock / 64];
+  __shared__ uint32_t pending[kShadeClasses][2 * kBlock];  // fewer than kBlock entries each between scans
   const uint32_t n = *countIn;
-  uint32_t nPending = 0;  // same value in every thread of the block
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t nPending[kShadeClasses] = {0u, 0u, 0u};  // same values in every thread of the block
+
+  auto shade_list = [&](int c, uint32_t count) {  // the first min(count, kBlock) entries of list c; called by all threads
+    bool alive = false;
+    Path p;
+    uint32_t pidWord = 0;
+    if (threadIdx.x < count)
+      alive = shade_entry(sc, in, hits, pending[c][threadIdx.x], samples, bounce, maxBounces, bsdfMode, p, pidWord);
+    const uint32_t carry = threadIdx.x + kBlock < count ? pending[c][threadIdx.x + kBlock] : 0u;
+    const uint32_t dst = block_append(alive, countOut, lds);  // synchronises the block
+    if (alive) store_path(out, dst, p, pidWord);
+    if (threadIdx.x + kBlock < count) pending[c][threadIdx.x] = carry;
+  };
+
   for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
     const uint32_t i = base + threadIdx.x;
-    bool isHit = false;
+    uint32_t cls = kShadeClasses;  // none
     if (i < n) {
-      if (hits[i].x == kInfinity) {  // path_tracing.comp:220-223 — assignment: radiance gathered so far is dropped
+      const float4 h = hits[i];
+      if (h.x == kInfinity) {  // path_tracing.comp:220-223 — assignment: radiance gathered so far is dropped
         const float4 m = in.m[i];
         const f3 s = f3{m.x, m.y, m.z} * 0.2f;
         samples[as_uint(in.o[i].w) & ~kAccStored] = make_float4(s.x, s.y, s.z, 0.0f);
       } else {
-        isHit = true;
+        cls = likely_lobe(sc.oshade[as_uint(h.y)]);
       }
     }
-    uint32_t nHits;
-    const uint32_t rank = block_rank(isHit, lds, nHits);
-    if (isHit) pending[nPending + rank] = i;
-    nPending += nHits;
-    __syncthreads();
-    if (nPending >= (uint32_t)kBlock) {
-      Path p;
-      uint32_t pidWord;
-      const bool alive = shade_entry(sc, in, hits, pending[threadIdx.x], samples, bounce, maxBounces, bsdfMode, p, pidWord);
-      const uint32_t carry = threadIdx.x + kBlock < nPending ? pending[threadIdx.x + kBlock] : 0u;
-      const uint32_t dst = block_append(alive, countOut, lds);  // synchronises the block
-      if (alive) store_path(out, dst, p, pidWord);
-      nPending -= kBlock;
-      if (threadIdx.x < nPending) pending[threadIdx.x] = carry;
-      // the next writer of pending[] comes after block_rank's barriers
+    // ranks within the block, per class
+    uint32_t below[kShadeClasses];
+    for (int c = 0; c < kShadeClasses; ++c) {
+      const unsigned long long b = __ballot(cls == (uint32_t)c);
+      below[c] = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      if ((threadIdx.x & 63u) == 0u) waveCount[c][wave] = (uint32_t)__popcll(b);
     }
-  }
-  if (nPending > 0) {
     __syncthreads();
-    bool alive = false;
-    Path p;
-    uint32_t pidWord = 0;
-    if (threadIdx.x < nPending)
-      alive = shade_entry(sc, in, hits, pending[threadIdx.x], samples, bounce, maxBounces, bsdfMode, p, pidWord);
-    const uint32_t dst = block_append(alive, countOut, lds);
-    if (alive) store_path(out, dst, p, pidWord);
+    for (int c = 0; c < kShadeClasses; ++c) {
+      uint32_t before = 0, total = 0;
+      for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const uint32_t k = waveCount[c][w];
+        if (w < wave) before += k;
+        total += k;
+      }
+      if (cls == (uint32_t)c) pending[c][nPending[c] + before + below[c]] = i;
+      nPending[c] += total;
+    }
+    __syncthreads();
+    for (int c = 0; c < kShadeClasses; ++c) {
+      if (nPending[c] >= (uint32_t)kBlock) {
+        shade_list(c, nPending[c]);
+        nPending[c] -= kBlock;
+      }
+    }
+    __syncthreads();  // waveCount and pending are rewritten by the next scan
   }
+  for (int c = 0; c < kShadeClasses; ++c)
+    if (nPending[c] > 0) shade_list(c, nPending[c]);
 }
 
 // Adds the finished frames to the accumulation image in frame order
