@@ -56,7 +56,7 @@ def cpu_baseline(scene, ubos, width, height, bounces, frames):
     """Times the CPU oracle (OpenMP over pixels) on a bounded sample of the same workload and returns
     (baseline dict, oracle work counters of the sample)."""
     from oracle import binding as O
-    osc = O.OracleScene(scene.objects, scene.object_bvh, scene.vertices, scene.mesh_bvh)
+    osc = O.OracleScene(scene.objects, scene.object_bvh, scene.vertices, scene.mesh_bvh, getattr(scene, "textures", ()))
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     if frames <= 0:
         t0 = time.perf_counter()
@@ -70,6 +70,16 @@ def cpu_baseline(scene, ubos, width, height, bounces, frames):
             "sample": f"{frames} frame(s) of {width}x{height}, {bounces} bounces, same scene and seeds "
                       f"({st['segments']} segments in {dt:.2f} s)"}
     return base, st
+
+
+def traversal_counters(scene, ubos, width, height, bounces):
+    """Oracle work counters (nodes and triangles per segment) from one frame at a quarter of the
+    resolution: enough for the per-segment means the roofline needs, in well under a second."""
+    from oracle import binding as O
+    osc = O.OracleScene(scene.objects, scene.object_bvh, scene.vertices, scene.mesh_bvh, getattr(scene, "textures", ()))
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    _, st = O.render_frames(osc, ubos[:1], max(16, width // 4), max(16, height // 4), bounces, threads=threads)
+    return st
 
 
 def main():
@@ -220,8 +230,10 @@ def main():
         }
         cpu = None
         counters = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N=1 only
             cpu, counters = cpu_baseline(scene, ubos, args.width, args.height, args.bounces, args.cpu_frames)
+        else:
+            counters = traversal_counters(scene, ubos, args.width, args.height, args.bounces)
         result["cpu_baseline"] = cpu
         # roofline of the dominant kernel (k_extend): algorithmic bytes per traced segment =
         # 64 B per inner node visited (both child boxes) ... stated in interchange terms as
