@@ -18,6 +18,14 @@
 
 namespace lpt {
 
+#ifdef LPT_EXTEND_STATS
+// analysis aid: [2k] rounds (or burst iterations) of kind k, [2k+1] lanes that took part
+__device__ unsigned long long g_extendStats[16];
+#define LPT_XSTAT(k, lanes) (++xsR[k], xsL[k] += (uint32_t)(lanes))
+#else
+#define LPT_XSTAT(k, lanes) ((void)0)
+#endif
+
 // Rays are handed out in chunks of kFetchChunk.  The queue is cut into kCursorRegions equal
 // regions with one cursor each (a single atomic word would serialise all waves); a wave
 // starts in the region of its workgroup and moves on to the next one when it runs dry.
@@ -92,6 +100,9 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
   uint32_t cur = kRefSentinel, rayIdx = 0;
   int sp = 0;
 
+#ifdef LPT_EXTEND_STATS
+  uint32_t xsR[8] = {}, xsL[8] = {};
+#endif
   for (;;) {
     const unsigned long long bF = __ballot(state == kStFetch);
     const unsigned long long bI = __ballot(state == kStInner);
@@ -106,6 +117,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
 
     // Idle lanes are pure loss, so refill as soon as a fair number waits (or nothing else is left).
     if (nF > 0 && (nF >= LPT_FETCH_THRESHOLD || busy == 0)) {
+      LPT_XSTAT(0, nF);
       while (!exhausted && chunkNext >= chunkEnd) {
         const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
         uint32_t b = 0;
@@ -146,6 +158,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         chunkNext += min((uint32_t)nF, avail);
       }
     } else if (nI >= nT && nI >= nO) {
+      LPT_XSTAT(1, nI);
       if (state == kStInner) {
         if (BURST && KN == 0) {
           bool mine = true;
@@ -163,6 +176,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
             }
             const int left = __popcll(__ballot(mine));
             if (left == 0 || LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
+            LPT_XSTAT(4, left);
           }
           stepped = true;  // `cur` already holds the next reference
         } else {
@@ -184,6 +198,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         }
       }
     } else if (nT >= nO) {
+      LPT_XSTAT(2, nT);
       if (state == kStTri) {
         if (BURST && KT == 0) {
           for (int it = 1;; ++it) {
@@ -199,6 +214,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
               ++triI;
             }
             const int left = __popcll(__ballot(triI < triEnd));
+            if (left) LPT_XSTAT(5, left);
             if (left == 0 || (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT)) break;
           }
         } else if (triI < triEnd) {
@@ -224,6 +240,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         }
       }
     } else {
+      LPT_XSTAT(3, nO);
       if (state == kStObj) {
         const uint32_t first = leaf_first(cur);
         const uint32_t count = leaf_count(cur);
@@ -278,6 +295,13 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       }
     }
   }
+#ifdef LPT_EXTEND_STATS
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) {
+      atomicAdd(&g_extendStats[2 * k], (unsigned long long)xsR[k]);
+      atomicAdd(&g_extendStats[2 * k + 1], (unsigned long long)xsL[k]);
+    }
+#endif
 }
 
 }  // namespace lpt

@@ -1239,6 +1239,16 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   unsigned long long totals[2] = {0, 0};
   LPT_HIP(c, hipMemcpy(totals, c->dTotals, sizeof totals, hipMemcpyDeviceToHost));
+#ifdef LPT_EXTEND_STATS
+  {
+    unsigned long long t[16];
+    LPT_HIP(c, hipMemcpyFromSymbol(t, HIP_SYMBOL(lpt::g_extendStats), sizeof t));
+    const char* names[6] = {"fetch", "inner", "tri", "obj", "inner+", "tri+"};
+    for (int k = 0; k < 6; ++k)
+      std::fprintf(stderr, "extend rounds %-7s %12llu  lanes/round %.1f\n", names[k], t[2 * k],
+                   t[2 * k] ? (double)t[2 * k + 1] / (double)t[2 * k] : 0.0);
+  }
+#endif
 #ifdef LPT_TRACE_STATS
   {
     unsigned long long t[16];
