@@ -46,3 +46,28 @@ def test_basic_bsdf_matches_oracle(device, cornell, cornell_oracle):
     img, gst = _render_gpu(device, cornell, ubos, w, h, 6, bsdf=L.BSDF_BASIC)
     assert gst.segments == st["segments"]
     assert rel_l2(img, ref) <= TOL
+
+
+@pytest.mark.gpu
+def test_full_size_config_properties(device, cornell):
+    """The benchmark's configuration at full size (1920x1080, 64 spp, 8 bounces), where the oracle is too
+    slow to compare against: properties that do not depend on size.  The three kernel organisations
+    produce the same bits; alpha counts the samples; one batch of 64 frames equals 64 batches of one;
+    paths = W*H*spp and every path traces between 1 and 8 segments."""
+    w, h, spp, bounces = 1920, 1080, 64, 8
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, spp)
+    images, segments = [], []
+    for pipeline, fif in ((L.PIPELINE_WAVEFRONT, 0), (L.PIPELINE_PERSISTENT, 0), (L.PIPELINE_WAVEFRONT, 1),
+                          (L.PIPELINE_MEGAKERNEL, 0)):
+        img, st = _render_gpu(device, cornell, ubos, w, h, bounces, pipeline=pipeline, fif=fif)
+        assert st.paths == w * h * spp
+        assert st.paths <= st.segments <= bounces * st.paths
+        assert np.all(img[..., 3] == spp)
+        assert np.isfinite(img[..., :3]).all() and img[..., :3].min() >= 0.0
+        images.append(img)
+        segments.append(st.segments)
+    assert len(set(segments)) == 1
+    for other in images[1:]:
+        assert np.array_equal(images[0], other)
+    # throughput never exceeds 1, so a path gathers at most emission (5) per bounce
+    assert images[0][..., :3].max() <= spp * 5.0 * bounces
