@@ -527,7 +527,7 @@ struct Partition {
   int dense;         // 1 if every slot of this rank is a pixel inside the image
 };
 
-__device__ __forceinline__ bool slot_to_pixel(const Partition& P, uint32_t slot, int& x, int& y) {
+__host__ __device__ __forceinline__ bool slot_to_pixel(const Partition& P, uint32_t slot, int& x, int& y) {
   uint32_t perTile = (uint32_t)(P.tileW * P.tileH);
   uint32_t k = slot / perTile, r = slot - k * perTile;
   uint32_t g = k * (uint32_t)P.nRanks + (uint32_t)P.rank;

@@ -84,27 +84,22 @@ __device__ __forceinline__ void store_path(const Queue& q, uint32_t slot, const 
 
 // ---- wavefront kernels ---------------------------------------------------------------
 
-// Camera rays for `nFrames` frames of the owned pixels (path id = frame*nSlots + slot).
-// `dense` = every slot is a pixel of the image: path pid goes to queue slot pid and the host
-// sets the queue count; otherwise slots outside the image are skipped by compaction.
+// Camera rays for `nFrames` frames of the owned pixels (path id = frame*nSlots + slot).  The queue
+// is filled densely and without atomics: `validBefore[slot]` is the number of slots below `slot`
+// that are pixels of the image (null if every slot is one), `nValid` their total, so the ray of
+// (frame f, slot) goes to f*nValid + validBefore[slot]; the host sets the queue count.
 __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
-                                                     Queue q, uint32_t* count, int dense) {
-  __shared__ uint32_t lds[kBlock / 64 + 1];
+                                                     Queue q, const uint32_t* __restrict__ validBefore,
+                                                     uint32_t nValid) {
   const uint32_t total = nFrames * P.nSlots;
-  for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
-    uint32_t pid = base + threadIdx.x;
-    bool active = false;
-    Path p;
-    if (pid < total) {
-      uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
-      int x, y;
-      if (slot_to_pixel(P, slot, x, y)) {
-        generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
-        active = true;
-      }
+  for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < total; pid += gridDim.x * kBlock) {
+    const uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
+    int x, y;
+    if (slot_to_pixel(P, slot, x, y)) {
+      Path p;
+      generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
+      store_path(q, validBefore ? f * nValid + validBefore[slot] : pid, p, pid);
     }
-    uint32_t dst = dense ? pid : block_append(active, count, lds);
-    if (active) store_path(q, dst, p, pid);
   }
 }
 
@@ -440,6 +435,8 @@ struct lpt_ctx {
   bool sized = false;
   float4* dAccum = nullptr;
   float4* dImage = nullptr;  // scan-line staging for read-back / resolve
+  uint32_t* dValidBefore = nullptr;  // per slot: pixels of the image among the lower slots (null: all slots are)
+  uint32_t nValid = 0;               // slots that are pixels of the image
 
   // options
   int maxBounces = 10;  // MAX_TRACE_DEPTH, shaders/path_tracing.comp:20
@@ -709,14 +706,12 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
   LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorRegions) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   uint32_t* cursors = c->dCounts + c->poolBounces;
-  const int dense = c->part.dense ? 1 : 0;
-  if (dense) {
-    // every slot is a pixel: the first queue is filled in path-id order, its count is known here
-    c->hUbos[frames].seed[0] = (uint32_t)paths;  // staging word behind the frame blocks
-    LPT_HIP(c, hipMemcpyAsync(c->dCounts, &c->hUbos[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  }
-  hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
-                     (uint32_t)frames, c->queues[0], c->dCounts, dense);
+  // the first queue is filled in path-id order, its count is known here
+  c->hUbos[frames].seed[0] = (uint32_t)frames * c->nValid;  // staging word behind the frame blocks
+  LPT_HIP(c, hipMemcpyAsync(c->dCounts, &c->hUbos[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  if (c->nValid)
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
+                       (uint32_t)frames, c->queues[0], c->dValidBefore, c->nValid);
   rc = ensure_events(c, c->evUsed + 2 * (size_t)nB);
   if (rc) return rc;
   for (uint32_t b = 0; b < nB; ++b) {
@@ -804,7 +799,21 @@ int set_partition(lpt_ctx* c, int W, int H, int tileW, int tileH, int rank, int 
   P.dense = (W % tileW == 0 && H % tileH == 0 && (P.tilesX * P.tilesY) % nRanks == 0) ? 1 : 0;
   dfree(c->dAccum);
   dfree(c->dImage);
+  dfree(c->dValidBefore);
   LPT_HIP(c, hipSetDevice(c->device));
+  c->nValid = P.nSlots;
+  if (!P.dense) {
+    std::vector<uint32_t> before(P.nSlots);
+    uint32_t nValid = 0;
+    for (uint32_t s = 0; s < P.nSlots; ++s) {
+      int x, y;
+      before[s] = nValid;
+      if (slot_to_pixel(P, s, x, y)) ++nValid;
+    }
+    LPT_HIP(c, hipMalloc(&c->dValidBefore, slots * sizeof(uint32_t)));
+    LPT_HIP(c, hipMemcpy(c->dValidBefore, before.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->nValid = nValid;
+  }
   LPT_HIP(c, hipMalloc(&c->dAccum, slots * sizeof(float4)));
   LPT_HIP(c, hipMalloc(&c->dImage, (size_t)W * H * sizeof(float4)));
   LPT_HIP(c, hipMemsetAsync(c->dAccum, 0, slots * sizeof(float4), c->stream));
@@ -878,6 +887,7 @@ void lpt_destroy(lpt_ctx* c) {
   free_pool(c);
   dfree(c->dAccum);
   dfree(c->dImage);
+  dfree(c->dValidBefore);
   dfree(c->dUbos);
   dfree(c->dTotals);
   if (c->hUbos) (void)hipHostFree(c->hUbos);
