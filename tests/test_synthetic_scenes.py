@@ -78,3 +78,43 @@ def test_cornell_like_parity_16_bounces(device, tmp_path):
     device.render_frames(ubos)
     assert device.stats().segments == st["segments"]
     assert np.array_equal(device.read_accum(), ref)
+
+
+def _tiny_scene(path, with_degenerate):
+    """One emissive triangle seen by the camera (object tree and mesh tree are single leaves); optionally a
+    zero-area triangle and a triangle seen edge-on, whose Moeller-Trumbore determinants are 0 (1/0 = inf,
+    0*inf = NaN must fall out through the comparisons as in shaders/common/ray.glsl:63-82)."""
+    g = scenes._GltfBuilder()
+    m = g.material("M", (0.7, 0.6, 0.5, 1), 0.3, 0.4, emissive=(1.0, 0.5, 0.25))
+    tri = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    nrm = np.tile([0, 0, 1], (3, 1)).astype(np.float32)
+    g.node("Tri", mesh=g.mesh("Tri", [(tri, nrm, np.array([0, 1, 2], np.uint32), m)]))
+    if with_degenerate:
+        bad = np.array([[0.2, 0.2, 1], [0.2, 0.2, 1], [0.2, 0.2, 1],        # zero area
+                        [0, -0.5, 0.5], [0, 0.5, 0.5], [0, 0, 2.5]], np.float32)  # in the plane x = 0: edge-on
+        g.node("Bad", mesh=g.mesh("Bad", [(bad, np.tile([0, 0, 1], (6, 1)).astype(np.float32),
+                                           np.array([0, 1, 2, 3, 4, 5], np.uint32), m)]))
+    g.node("Camera", camera=g.camera(0.8), translation=(0, 0, 4))
+    g.write(path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_degenerate", [False, True])
+def test_tiny_and_degenerate_scenes_match_oracle(device, tmp_path, with_degenerate):
+    path = str(tmp_path / "tiny.gltf")
+    _tiny_scene(path, with_degenerate)
+    s = L.Scene(path, builder=L.BUILDER_BINNED_SAH)
+    assert len(s.objects) == (2 if with_degenerate else 1)
+    osc = O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
+    device.upload_scene(s)
+    for (w, h, bounces, frames) in ((37, 23, 3, 2), (1, 1, 1, 1), (8, 8, 16, 3)):  # ragged sizes, one pixel, deep
+        ubos = L.frame_ubos(s.camera_world, s.fov_y, frames, seed=11)
+        ref, st = O.render_frames(osc, ubos, w, h, bounces)
+        for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_MEGAKERNEL, L.PIPELINE_PERSISTENT):
+            device.resize(w, h)
+            device.set_options(bounces, L.BSDF_HEITZ, pipeline, 0)
+            device.render_frames(ubos)
+            img = device.read_accum()
+            assert device.stats().segments == st["segments"]
+            assert np.array_equal(np.isnan(img), np.isnan(ref))
+            assert np.array_equal(np.nan_to_num(img, nan=-1.0), np.nan_to_num(ref, nan=-1.0)), (w, h, pipeline)
