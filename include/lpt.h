@@ -89,7 +89,11 @@ typedef enum lpt_status {
 
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
-/* Kernel organisation.  Both produce identical pixels. */
+/* Kernel organisation; all three produce identical pixels.
+ * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (fastest;
+ *            128 bytes of queues per path in flight).
+ * MEGAKERNEL: one thread per pixel runs the whole path (the shader's own organisation).
+ * PERSISTENT: one launch per batch, paths stay in registers (16 bytes per path in flight). */
 enum { LPT_PIPELINE_WAVEFRONT = 0, LPT_PIPELINE_MEGAKERNEL = 1, LPT_PIPELINE_PERSISTENT = 2 };
 /* Mesh BVH builders offered by lpt_build_mesh_bvh. */
 enum { LPT_BVH_LBVH = 0 };
@@ -167,7 +171,8 @@ int lpt_set_partition(lpt_ctx* ctx, int tile_w, int tile_h, int rank, int n_rank
 /* ---- rendering: the dispatch of src/RendererPT.cpp:527-533 ------------------ */
 
 /* MAX_TRACE_DEPTH (shaders/path_tracing.comp:20), BSDF family (:22), kernel
- * organisation, and how many frames may be in flight at once (0 = automatic). */
+ * organisation, and how many frames may be in flight at once (0 = automatic: up to
+ * 256 Mi paths, fewer if device memory is short). */
 int lpt_set_options(lpt_ctx* ctx, int max_bounces, int bsdf_mode, int pipeline, int frames_in_flight);
 
 /* Renders n_frames consecutive frames (one sample per pixel each), frame i with
