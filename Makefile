@@ -24,7 +24,7 @@ $(LIBDIR)/liblpt_hip.so: $(CSRC)/lpt_trace.h $(CSRC)/lpt_hip.hip $(CSRC)/lpt_lbv
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/lpt_hip.hip $(CSRC)/lpt_lbvh.hip
 
 $(LIBDIR)/liblpt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/liblpt_hip.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -L$(LIBDIR) -llpt_hip -lz -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRCS) -L$(LIBDIR) -llpt_hip -lz -pthread -Wl,-rpath,'$$ORIGIN'
 
 $(LIBDIR)/lpt_render: $(HOST)/main.cpp $(LIBDIR)/liblpt_host.so
 	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp -L$(LIBDIR) -llpt_host -llpt_hip -Wl,-rpath,'$$ORIGIN'

@@ -1,8 +1,12 @@
 #include "pt_scene_converter.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
+#include <string>
+#include <thread>
 
 namespace {
 
@@ -36,8 +40,19 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
   reset();
   if (!scene) throw std::runtime_error("PTSceneConverter::loadScene: null scene");
 
-  std::vector<lsg::AABB<float>> worldBoxes;       // one per sub-mesh instance
-  std::vector<GPUObjectData> pendingObjects;      // in scene-graph order, before BVH ordering
+  // One job per (object, sub-mesh): the object record is filled while walking the graph (which
+  // also fixes the order of the textures); the mesh trees are then built on several host threads
+  // and appended in the walk's order, so the buffers do not depend on the number of threads.
+  struct Job {
+    GPUObjectData od;
+    lsg::mat4 world;
+    lsg::Ref<lsg::Geometry> geometry;
+    std::vector<GPUBVHNode> nodes;
+    std::vector<GPUVertex> vertices;
+    lsg::AABB<float> localBounds;
+    std::string error;
+  };
+  std::vector<Job> jobs;
 
   auto visit = [&](const lsg::Ref<lsg::Object>& object) -> bool {
     lsg::mat4 world;  // identity when the object carries no transform
@@ -55,8 +70,8 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
         if (verbose_) std::cout << "Unknown material. Skipping submesh." << std::endl;
         continue;
       }
-
-      GPUObjectData od;
+      Job job;
+      GPUObjectData& od = job.od;
       std::memset(&od, 0, sizeof od);
       const lsg::mat4 inv = lsg::inverse(world);
       std::memcpy(od.worldMatrix, world.m, sizeof od.worldMatrix);
@@ -77,69 +92,100 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
       od.transmissionTexture =
           material->transmissionTexture() ? copyTextureToGPU(material->transmissionTexture()) : kNoTexture;
       od.normalTexture = material->normalTex() ? copyTextureToGPU(material->normalTex()) : kNoTexture;
-      // element indices, not byte offsets (src/PTSceneConverter.cpp:87-88)
-      od.bvhOffset = (uint32_t)meshBVHNodes_.size();
-      od.verticesOffset = (uint32_t)vertices_.size();
-
-      auto geometry = sub->geometry();
-      auto posAcc = geometry->getTrianglePositionAccessor();
-      auto nrmAcc = geometry->getTriangleNormalAccessor();
-      auto uvAcc = geometry->hasUv(0u) ? geometry->getTriangleUVAccessor(0u) : nullptr;
-      const uint32_t nTris = (uint32_t)posAcc->count();
-
-      // mesh tree + triangle order of its leaves
-      std::vector<uint32_t> order;
-      lsg::AABB<float> localBounds;
-      if (meshBuilder_ == MeshBuilder::LBVH) {
-        if (!device_) throw std::runtime_error("PTSceneConverter: the LBVH builder needs a device context");
-        std::vector<float> corners(9 * (size_t)nTris);
-        for (uint32_t t = 0; t < nTris; ++t) {
-          auto T = (*posAcc)[t];
-          const lsg::vec3 c[3] = {T.a(), T.b(), T.c()};
-          for (int k = 0; k < 3; ++k) {
-            corners[9 * (size_t)t + 3 * k + 0] = c[k].x;
-            corners[9 * (size_t)t + 3 * k + 1] = c[k].y;
-            corners[9 * (size_t)t + 3 * k + 2] = c[k].z;
-            localBounds.expand(c[k]);
-          }
-        }
-        std::vector<GPUBVHNode> nodes(nTris ? 2 * (size_t)nTris : 1);
-        order.resize(nTris);
-        uint32_t nNodes = 0;
-        int rc = lpt_build_mesh_bvh(device_, LPT_BVH_LBVH, corners.data(), nTris, nodes.data(), &nNodes, order.data());
-        if (rc != LPT_OK) throw std::runtime_error(std::string("lpt_build_mesh_bvh: ") + lpt_last_error(device_));
-        meshBVHNodes_.insert(meshBVHNodes_.end(), nodes.begin(), nodes.begin() + nNodes);
-      } else {
-        lsg::bvh::BuildOptions opt = buildOptions_;
-        opt.spatialSplits = meshBuilder_ == MeshBuilder::SplitBVH;
-        lsg::bvh::SplitBVHBuilder<float> builder(opt);
-        auto bvh = builder.process(posAcc);
-        for (const auto& node : bvh->getNodes()) meshBVHNodes_.push_back(packNode(node));
-        order = bvh->getPrimitiveIndices();
-        localBounds = bvh->getBounds();
-      }
-
-      // de-indexed, interleaved vertices in leaf order (src/PTSceneConverter.cpp:105-120)
-      for (uint32_t idx : order) {
-        auto P = (*posAcc)[idx];
-        auto N = (*nrmAcc)[idx];
-        if (uvAcc) {
-          auto U = (*uvAcc)[idx];
-          vertices_.push_back(packVertex(P.a(), N.a(), U.a()));
-          vertices_.push_back(packVertex(P.b(), N.b(), U.b()));
-          vertices_.push_back(packVertex(P.c(), N.c(), U.c()));
-        } else {
-          vertices_.push_back(packVertex(P.a(), N.a(), {}));
-          vertices_.push_back(packVertex(P.b(), N.b(), {}));
-          vertices_.push_back(packVertex(P.c(), N.c(), {}));
-        }
-      }
-      worldBoxes.push_back(localBounds.transform(world));
-      pendingObjects.push_back(od);
+      job.world = world;
+      job.geometry = sub->geometry();
+      jobs.push_back(std::move(job));
     }
     return true;
   };
   for (const auto& root : scene->children()) root->traverseDown(visit);
+
+  // mesh tree + de-indexed, interleaved vertices in leaf order (src/PTSceneConverter.cpp:97-120)
+  auto buildJob = [&](Job& job) {
+    auto posAcc = job.geometry->getTrianglePositionAccessor();
+    auto nrmAcc = job.geometry->getTriangleNormalAccessor();
+    auto uvAcc = job.geometry->hasUv(0u) ? job.geometry->getTriangleUVAccessor(0u) : nullptr;
+    const uint32_t nTris = (uint32_t)posAcc->count();
+    std::vector<uint32_t> order;
+    if (meshBuilder_ == MeshBuilder::LBVH) {
+      if (!device_) throw std::runtime_error("PTSceneConverter: the LBVH builder needs a device context");
+      std::vector<float> corners(9 * (size_t)nTris);
+      for (uint32_t t = 0; t < nTris; ++t) {
+        auto T = (*posAcc)[t];
+        const lsg::vec3 c[3] = {T.a(), T.b(), T.c()};
+        for (int k = 0; k < 3; ++k) {
+          corners[9 * (size_t)t + 3 * k + 0] = c[k].x;
+          corners[9 * (size_t)t + 3 * k + 1] = c[k].y;
+          corners[9 * (size_t)t + 3 * k + 2] = c[k].z;
+          job.localBounds.expand(c[k]);
+        }
+      }
+      job.nodes.resize(nTris ? 2 * (size_t)nTris : 1);
+      order.resize(nTris);
+      uint32_t nNodes = 0;
+      int rc = lpt_build_mesh_bvh(device_, LPT_BVH_LBVH, corners.data(), nTris, job.nodes.data(), &nNodes, order.data());
+      if (rc != LPT_OK) throw std::runtime_error(std::string("lpt_build_mesh_bvh: ") + lpt_last_error(device_));
+      job.nodes.resize(nNodes);
+    } else {
+      lsg::bvh::BuildOptions opt = buildOptions_;
+      opt.spatialSplits = meshBuilder_ == MeshBuilder::SplitBVH;
+      lsg::bvh::SplitBVHBuilder<float> builder(opt);
+      auto bvh = builder.process(posAcc);
+      for (const auto& node : bvh->getNodes()) job.nodes.push_back(packNode(node));
+      order = bvh->getPrimitiveIndices();
+      job.localBounds = bvh->getBounds();
+    }
+    job.vertices.reserve(3 * order.size());
+    for (uint32_t idx : order) {
+      auto P = (*posAcc)[idx];
+      auto N = (*nrmAcc)[idx];
+      if (uvAcc) {
+        auto U = (*uvAcc)[idx];
+        job.vertices.push_back(packVertex(P.a(), N.a(), U.a()));
+        job.vertices.push_back(packVertex(P.b(), N.b(), U.b()));
+        job.vertices.push_back(packVertex(P.c(), N.c(), U.c()));
+      } else {
+        job.vertices.push_back(packVertex(P.a(), N.a(), {}));
+        job.vertices.push_back(packVertex(P.b(), N.b(), {}));
+        job.vertices.push_back(packVertex(P.c(), N.c(), {}));
+      }
+    }
+  };
+  // the GPU builder uses one device context: serial; the host builders run one job per thread at a time
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const unsigned nThreads = meshBuilder_ == MeshBuilder::LBVH ? 1u : std::min<unsigned>(hw, (unsigned)std::max<size_t>(1, jobs.size()));
+  std::atomic<size_t> nextJob{0};
+  auto worker = [&]() {
+    for (size_t j; (j = nextJob.fetch_add(1)) < jobs.size();) {
+      try {
+        buildJob(jobs[j]);
+      } catch (const std::exception& e) {
+        jobs[j].error = e.what()[0] ? e.what() : "mesh conversion failed";
+      }
+    }
+  };
+  if (nThreads <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nThreads; ++t) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+  }
+
+  std::vector<lsg::AABB<float>> worldBoxes;       // one per sub-mesh instance
+  std::vector<GPUObjectData> pendingObjects;      // in scene-graph order, before BVH ordering
+  for (Job& job : jobs) {
+    if (!job.error.empty()) throw std::runtime_error(job.error);
+    // element indices, not byte offsets (src/PTSceneConverter.cpp:87-88)
+    job.od.bvhOffset = (uint32_t)meshBVHNodes_.size();
+    job.od.verticesOffset = (uint32_t)vertices_.size();
+    meshBVHNodes_.insert(meshBVHNodes_.end(), job.nodes.begin(), job.nodes.end());
+    vertices_.insert(vertices_.end(), job.vertices.begin(), job.vertices.end());
+    worldBoxes.push_back(job.localBounds.transform(job.world));
+    pendingObjects.push_back(job.od);
+    job.nodes = {};
+    job.vertices = {};
+  }
 
   if (pendingObjects.empty()) throw std::runtime_error("PTSceneConverter: the scene contains no renderable geometry");
 
