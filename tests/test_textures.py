@@ -193,3 +193,32 @@ def test_texture_upload_errors(device, textured, cornell):
     with pytest.raises(L.LptError):
         device.upload_textures([{"pixels": np.zeros((2, 2, 4), np.uint8)}] * 513)
     device.upload_scene(cornell)  # an untextured scene still loads afterwards
+
+
+@pytest.mark.gpu
+def test_command_line_renderer_writes_the_same_image(textured, tmp_path, device):
+    """lpt_render (the headless stand-in for src/Main.cpp) on the textured scene: its PFM is the accumulation
+    image divided by the sample count, its PPM the tone-mapped display image (tex_to_quad.frag)."""
+    import subprocess
+    path, _, scene = textured
+    exe = os.path.join(os.path.dirname(L.__file__), "lib", "lpt_render")
+    w, h, spp, bounces = 96, 64, 5, 6
+    out = str(tmp_path / "img")
+    r = subprocess.run([exe, path, "--width", str(w), "--height", str(h), "--spp", str(spp), "--bounces", str(bounces),
+                        "--seed", "0x5EED", "--out", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    # same frames through the Python binding of the C-ABI
+    device.upload_scene(scene)
+    device.resize(w, h)
+    device.set_options(bounces, L.BSDF_HEITZ, L.PIPELINE_WAVEFRONT, 0)
+    device.render_frames(L.frame_ubos(scene.camera_world, scene.fov_y, spp, seed=0x5EED))
+    acc = device.read_accum()
+    with open(out + ".pfm", "rb") as f:
+        assert f.readline() == b"PF\n" and f.readline() == f"{w} {h}\n".encode() and f.readline() == b"-1.0\n"
+        pfm = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+    assert np.array_equal(pfm, acc[..., :3] * np.float32(1.0 / spp))
+    with open(out + ".ppm", "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == f"{w} {h}\n".encode() and f.readline() == b"255\n"
+        ppm = np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
+    disp = np.clip(O.resolve(acc, 1.0 / spp)[..., :3], 0.0, 1.0)
+    assert np.abs(ppm.astype(np.int32) - (disp * 255.0 + 0.5).astype(np.int32)).max() <= 1
