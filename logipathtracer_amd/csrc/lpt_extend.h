@@ -4,13 +4,22 @@
 // triangle tests that intersect_scene (lpt_device.h) performs, so hits are identical.
 // What differs is the scheduling across the 64 lanes of a wave: a lane's traversal is
 // cut into unit steps of four kinds — FETCH a new ray, one INNER node (two box tests),
-// one TRIangle test, enter one OBJect — and in each round the wave runs the kind that
+// one TRIangle leaf, enter one OBJect — and in each round the wave runs the kind that
 // most lanes are waiting for.  Lanes of other kinds simply wait; waiting never changes a
 // lane's own sequence.  This keeps the SIMD lanes of each issued instruction well filled
 // where a per-lane "if leaf / else inner" loop would run every branch with few lanes.
 //
+// A round of the INNER kind goes on in a short burst loop for the lanes whose next reference
+// is again an inner node, while enough of them remain; a round of the TRI kind finishes the
+// leaf.  The burst loops carry only the reference, the stack pointer and the hit, so they are
+// much shorter than a full round of the scheduler.
+//
 // Rays are handed out in chunks: one atomic on a global cursor per chunk and wave, the
 // chunk is then consumed lane by lane as rays finish (no idle tail inside a wave).
+//
+// The scene is read from global memory: its hot part sits in L1/L2 and the kernel is bound by
+// vector-ALU issue, so LDS copies of the hottest nodes, triangles and object records (tried
+// from 16 nodes per workgroup to 768 nodes + 512 triangles) were no faster.
 #pragma once
 #include "lpt_device.h"
 
@@ -34,7 +43,7 @@ constexpr uint32_t kCursorRegions = 8;
 #ifndef LPT_FETCH_THRESHOLD
 #define LPT_FETCH_THRESHOLD 16
 #endif
-// A burst goes on while left * DEN >= entered * NUM lanes remain in it.
+// An inner-node burst goes on while left * DEN >= entered * NUM lanes remain in it.
 #ifndef LPT_BURST_INNER_NUM
 #define LPT_BURST_INNER_NUM 1
 #define LPT_BURST_INNER_DEN 2
@@ -48,41 +57,13 @@ constexpr uint32_t kCursorRegions = 8;
 constexpr int kBurstTriFree = 4;
 constexpr int kStFetch = 0, kStInner = 1, kStTri = 2, kStObj = 3, kStDone = 4;
 
-// LDS image of one block: the traversal stacks plus the hottest prefix of the scene arrays
-// (they are stored hottest first).  KN nodes, KT triangles, KO object records.
-template <int S, int BLOCK, int KN, int KT, int KO>
-struct ExtendShared {
-  uint32_t stack[S * BLOCK];
-  float4 nodes[KN > 0 ? KN * 4 : 1];
-  float4 tris[KT > 0 ? KT * 3 : 1];
-  float4 objs[KO > 0 ? KO * 4 : 1];
-};
-
-// BURST: a round of the INNER or TRI kind keeps going for the lanes that stay in that kind (a
-// node whose children are inner nodes, a leaf with more triangles) while at least half of
-// the lanes that entered it still do.  The burst loop carries only the reference, the stack
-// pointer and the hit, so it is much shorter than a full round of the scheduler.
-template <int S, int BLOCK, int KN, int KT, int KO, bool BURST = false>
+// `stack` is the workgroup's LDS array of S entries per thread, laid out [entry][thread].
+template <int S, int BLOCK>
 __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4* __restrict__ qo,
                                                   const float4* __restrict__ qd, uint32_t n,
-                                                  float4* __restrict__ hits, uint32_t* cursor,
-                                                  ExtendShared<S, BLOCK, KN, KT, KO>& sh) {
-  uint32_t* stk = &sh.stack[threadIdx.x];
+                                                  float4* __restrict__ hits, uint32_t* cursor, uint32_t* stack) {
+  uint32_t* stk = &stack[threadIdx.x];
   const uint32_t lane = threadIdx.x & 63u;
-
-  // fill the LDS copies of the hot prefixes
-  const uint32_t hotNodes = min((uint32_t)KN, sc.nNodes);
-  const uint32_t hotTris = min((uint32_t)KT, sc.nTris);
-  const uint32_t hotObjs = min((uint32_t)KO, sc.nObjects);
-  if (KN > 0 || KT > 0 || KO > 0) {
-    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
-    const float4* gt = reinterpret_cast<const float4*>(sc.tris);
-    const float4* go = reinterpret_cast<const float4*>(sc.otrav);
-    for (uint32_t i = threadIdx.x; i < hotNodes * 4u; i += BLOCK) sh.nodes[i] = gn[i];
-    for (uint32_t i = threadIdx.x; i < hotTris * 3u; i += BLOCK) sh.tris[i] = gt[i];
-    for (uint32_t i = threadIdx.x; i < hotObjs * 4u; i += BLOCK) sh.objs[i] = go[i];
-    __syncthreads();
-  }
 
   // wave-uniform chunk of ray indices [chunkNext, chunkEnd)
   uint32_t chunkNext = 0, chunkEnd = 0;
@@ -160,79 +141,43 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     } else if (nI >= nT && nI >= nO) {
       LPT_XSTAT(1, nI);
       if (state == kStInner) {
-        if (BURST && KN == 0) {
-          bool mine = true;
-          for (;;) {
-            if (mine) {
-              const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-              const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-              bool h0, h1;
-              box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
-              const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-              if (h0 && h1) stk[(sp++) * BLOCK] = r0;
-              cur = h1 ? r1 : r0;
-              if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
-              mine = cur < kRefMarker;  // still an inner node (marker, leaves and the sentinel are larger)
-            }
-            const int left = __popcll(__ballot(mine));
-            if (left == 0 || LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
-            LPT_XSTAT(4, left);
-          }
-          stepped = true;  // `cur` already holds the next reference
-        } else {
-          float4 q0, q1, q2, q3;
-          if (cur < hotNodes) {
-            const float4* q = &sh.nodes[cur * 4u];
-            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
-          } else {
+        bool mine = true;
+        for (;;) {
+          if (mine) {
             const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            bool h0, h1;
+            box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+            const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+            if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+            cur = h1 ? r1 : r0;
+            if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
+            mine = cur < kRefMarker;  // still an inner node (marker, leaves and the sentinel are larger)
           }
-          bool h0, h1;
-          box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
-          const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-          if (h0 && h1) stk[(sp++) * BLOCK] = r0;
-          cur = h1 ? r1 : r0;
-          needPop = !(h0 || h1);
-          stepped = true;
+          const int left = __popcll(__ballot(mine));
+          if (left == 0 || LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
+          LPT_XSTAT(4, left);
         }
+        stepped = true;  // `cur` already holds the next reference
       }
     } else if (nT >= nO) {
       LPT_XSTAT(2, nT);
       if (state == kStTri) {
-        if (BURST && KT == 0) {
-          for (int it = 1;; ++it) {
-            if (triI < triEnd) {
-              const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
-              const float4 a = tq[0], b = tq[1], c = tq[2];
-              const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
-              if (td > kEps && td < hit.t) {
-                hit.t = td;
-                hit.obj = curObj;
-                hit.prim = as_uint(a.w);
-              }
-              ++triI;
-            }
-            const int left = __popcll(__ballot(triI < triEnd));
-            if (left) LPT_XSTAT(5, left);
-            if (left == 0 || (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT)) break;
-          }
-        } else if (triI < triEnd) {
-          float4 a, b, c;
-          if (triI < hotTris) {
-            const float4* tq = &sh.tris[triI * 3u];
-            a = tq[0]; b = tq[1]; c = tq[2];
-          } else {
+        for (int it = 1;; ++it) {
+          if (triI < triEnd) {
             const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
-            a = tq[0]; b = tq[1]; c = tq[2];
+            const float4 a = tq[0], b = tq[1], c = tq[2];
+            const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
+            if (td > kEps && td < hit.t) {
+              hit.t = td;
+              hit.obj = curObj;
+              hit.prim = as_uint(a.w);
+            }
+            ++triI;
           }
-          const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
-          if (td > kEps && td < hit.t) {
-            hit.t = td;
-            hit.obj = curObj;
-            hit.prim = as_uint(a.w);
-          }
-          ++triI;
+          const int left = __popcll(__ballot(triI < triEnd));
+          if (left) LPT_XSTAT(5, left);
+          if (left == 0 || (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT)) break;
         }
         if (triI >= triEnd) {
           needPop = true;
@@ -249,14 +194,8 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         } else {
           if (count > 1u) stk[(sp++) * BLOCK] = make_leaf_ref(first + 1u, count - 1u);
           stk[(sp++) * BLOCK] = kRefMarker;
-          float4 r0, r1, r2, r3;
-          if (first < hotObjs) {
-            const float4* oq = &sh.objs[first * 4u];
-            r0 = oq[0]; r1 = oq[1]; r2 = oq[2]; r3 = oq[3];
-          } else {
-            const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
-            r0 = oq[0]; r1 = oq[1]; r2 = oq[2]; r3 = oq[3];
-          }
+          const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
+          const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
           co = xform_point(rows, wo);
           cd = xform_dir(rows, wd);

@@ -103,15 +103,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
   }
 }
 
-// Closest hit for every queued ray: persistent waves, node stacks and the hottest part of
-// the scene in LDS, rays handed out through `cursor` (zeroed before the launch).  See
-// lpt_extend.h.  BLOCK threads per workgroup, one workgroup per CU when the caches are used.
-template <int S, int BLOCK, int KN, int KT, int KO, bool BURST = false>
-__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, const float4* __restrict__ qo,
-                                                  const float4* __restrict__ qd, const uint32_t* __restrict__ count,
-                                                  float4* __restrict__ hits, uint32_t* cursor) {
-  __shared__ ExtendShared<S, BLOCK, KN, KT, KO> sh;
-  extend_persistent<S, BLOCK, KN, KT, KO, BURST>(sc, qo, qd, *count, hits, cursor, sh);
+// Closest hit for every queued ray: persistent waves, node stacks in LDS, rays handed out
+// through `cursor` (kCursorRegions words zeroed before the launch).  See lpt_extend.h.
+template <int S>
+__global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
+                                                   const float4* __restrict__ qd, const uint32_t* __restrict__ count,
+                                                   float4* __restrict__ hits, uint32_t* cursor) {
+  __shared__ uint32_t stack[S * kBlock];
+  extend_persistent<S, kBlock>(sc, qo, qd, *count, hits, cursor, stack);
 }
 
 // Shades queue entry i (a ray that hit something), samples the next direction, applies Russian
@@ -666,35 +665,32 @@ int grid_for(const lpt_ctx* c, size_t items, int blocksPerCU) {
   return (int)std::max<size_t>(1, std::min(need, cap));
 }
 
-template <int S, int BLOCK, int KN, int KT, int KO, bool BURST = false>
+template <int S>
 int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
-  // persistent grid sized by LDS residency (160 KiB per CU)
-  const size_t ldsBytes = sizeof(ExtendShared<S, BLOCK, KN, KT, KO>);
-  int perCU = std::max<int>(1, std::min<int>(2048 / BLOCK, (int)(160 * 1024 / ldsBytes)));
+  // persistent grid: exactly as many workgroups as are resident at once (registers and LDS decide)
+  static const int resident = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<S>, kBlock, 0) != hipSuccess || n < 1) n = 4;
+    return n;
+  }();
+  int perCU = resident;
   static const int capPerCU = std::getenv("LPT_EXTEND_BLOCKS_PER_CU") ? std::atoi(std::getenv("LPT_EXTEND_BLOCKS_PER_CU")) : 0;
   if (capPerCU > 0) perCU = std::min(perCU, capPerCU);
-  size_t need = (maxItems + BLOCK - 1) / BLOCK;
+  size_t need = (maxItems + kBlock - 1) / kBlock;
   int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
-  hipLaunchKernelGGL((k_extend<S, BLOCK, KN, KT, KO, BURST>), dim3(grid), dim3(BLOCK), 0, c->stream, device_scene(c), q.o,
-                     q.d, count, c->dHits, cursor);
+  hipLaunchKernelGGL(k_extend<S>, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), q.o, q.d, count, c->dHits,
+                     cursor);
   return 0;
 }
 
+// Stack depth of the kernel instance: the smallest that holds the uploaded trees.
 int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
-  // The traversal kernel is bound by vector-ALU issue, not by node fetches (the scene's hot part
-  // sits in L1/L2): measured on MI355X, 256-thread workgroups without LDS copies of the scene
-  // are as fast as or faster than every LDS-cached form tried (from 16 nodes per 256 threads to
-  // 768 nodes + 512 triangles per 1024 threads: 0 to -7 %).  LPT_EXTEND_VARIANT=1 selects the
-  // largest of them for experiments.
-  static const int variant = std::getenv("LPT_EXTEND_VARIANT") ? std::atoi(std::getenv("LPT_EXTEND_VARIANT")) : 0;
-  if (variant == 1 && c->stackNeed <= 20) return launch_extend<20, 1024, 768, 512, 32>(c, q, count, cursor, maxItems);
-  if (variant == 6 && c->stackNeed <= 20) return launch_extend<20, 256, 0, 0, 0, false>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 16) return launch_extend<16, 256, 0, 0, 0, true>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 20) return launch_extend<20, 256, 0, 0, 0, true>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 24) return launch_extend<24, 256, 0, 0, 0, true>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 32) return launch_extend<32, 256, 0, 0, 0, true>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 48) return launch_extend<48, 256, 0, 0, 0, true>(c, q, count, cursor, maxItems);
-  return launch_extend<64, 256, 0, 0, 0, true>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 16) return launch_extend<16>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 20) return launch_extend<20>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 24) return launch_extend<24>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 32) return launch_extend<32>(c, q, count, cursor, maxItems);
+  if (c->stackNeed <= 48) return launch_extend<48>(c, q, count, cursor, maxItems);
+  return launch_extend<64>(c, q, count, cursor, maxItems);
 }
 
 int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
@@ -732,9 +728,13 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
 
 template <int S>
 void launch_trace(lpt_ctx* c, int frames) {
-  // persistent grid: as many workgroups per CU as the LDS stacks allow (160 KiB per CU), at most 8
-  const size_t ldsBytes = sizeof(TraceShared<S, kBlock>);
-  int perCU = std::max<int>(1, std::min<int>(8, (int)(160 * 1024 / ldsBytes)));
+  // persistent grid: exactly as many workgroups as are resident at once (registers and LDS decide)
+  static const int resident = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<S>, kBlock, 0) != hipSuccess || n < 1) n = 4;
+    return n;
+  }();
+  int perCU = resident;
   static const int capPerCU = std::getenv("LPT_TRACE_BLOCKS_PER_CU") ? std::atoi(std::getenv("LPT_TRACE_BLOCKS_PER_CU")) : 0;
   if (capPerCU > 0) perCU = std::min(perCU, capPerCU);
   const size_t paths = (size_t)frames * c->part.nSlots;
