@@ -716,7 +716,12 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
+    static const int shadeResident = [] {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, 0) != hipSuccess || n < 1) n = 4;
+      return n;
+    }();
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, shadeResident)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
                        c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
   }
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
