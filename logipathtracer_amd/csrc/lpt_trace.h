@@ -234,30 +234,42 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
 
     if (nI >= nT && nI >= nO) {
       LPT_STAT(0, nI);
-      if (state == kTsInner) {
-        const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        bool h0, h1;
-        box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
-        const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-        if (h0 && h1) stk[(sp++) * BLOCK] = r0;
-        cur = h1 ? r1 : r0;
-        needPop = !(h0 || h1);
-        stepped = true;
+      if (state == kTsInner) {  // burst over consecutive inner nodes, as in k_extend
+        bool mine = true;
+        for (;;) {
+          if (mine) {
+            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            bool h0, h1;
+            box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+            const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+            if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+            cur = h1 ? r1 : r0;
+            if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
+            mine = cur < kRefMarker;
+          }
+          const int left = __popcll(__ballot(mine));
+          if (left == 0 || LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
+        }
+        stepped = true;  // `cur` already holds the next reference
       }
     } else if (nT >= nO) {
       LPT_STAT(1, nT);
       if (state == kTsTri) {
-        if (triI < triEnd) {
-          const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
-          const float4 a = tq[0], b = tq[1], c = tq[2];
-          const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
-          if (td > kEps && td < hit.t) {
-            hit.t = td;
-            hit.obj = curObj;
-            hit.prim = as_uint(a.w);
+        for (int it = 1;; ++it) {  // the whole leaf, as in k_extend
+          if (triI < triEnd) {
+            const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
+            const float4 a = tq[0], b = tq[1], c = tq[2];
+            const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
+            if (td > kEps && td < hit.t) {
+              hit.t = td;
+              hit.obj = curObj;
+              hit.prim = as_uint(a.w);
+            }
+            ++triI;
           }
-          ++triI;
+          const int left = __popcll(__ballot(triI < triEnd));
+          if (left == 0 || (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT)) break;
         }
         if (triI >= triEnd) {
           needPop = true;
@@ -296,15 +308,13 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     // decide what the lane waits for next.  Leaving an object's mesh tree restores the
     // world-space ray.
     if (stepped) {
-      if (needPop) {
+      if (needPop) cur = stk[(--sp) * BLOCK];
+      if (cur == kRefMarker) {  // only a pop yields the marker
+        inObj = false;
+        co = p.o;
+        cd = p.d;
+        cinv = winv;
         cur = stk[(--sp) * BLOCK];
-        if (cur == kRefMarker) {
-          inObj = false;
-          co = p.o;
-          cd = p.d;
-          cinv = winv;
-          cur = stk[(--sp) * BLOCK];
-        }
       }
       if (cur == kRefSentinel) {
         state = kTsShade;
