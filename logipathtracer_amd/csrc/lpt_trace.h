@@ -22,6 +22,10 @@ namespace lpt {
 #ifndef LPT_SURFACE_THRESHOLD
 #define LPT_SURFACE_THRESHOLD 32
 #endif
+// A surface round repeats the walk order while at least this many lanes are still in a walk.
+#ifndef LPT_WALK_STAY
+#define LPT_WALK_STAY 12
+#endif
 // Upper bound on the rounds of one wave, far above any real batch (a wave of a full-size batch
 // runs a few million): an exit every wave reaches even if a lane's state were corrupted.
 #ifndef LPT_TRACE_ROUND_LIMIT
@@ -128,14 +132,21 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
           state = kTsWalk;
         }
       }
-      if (state == kTsWalk && !finish && !ended) {
-        const float alpha = sf.roughness * sf.roughness;
-        const float iorOut = sf.outside ? 1.0f : sf.ior;
-        const float iorIn = sf.outside ? sf.ior : 1.0f;
-        if (heitz_walk_step(p.rng, walk, sf.interaction, sf.baseLinear, alpha, iorOut, iorIn)) {
-          weight = heitz_walk_result(walk, sf.interaction, sf.baseLinear, lightDir);
-          finish = true;
+      // walk orders: all lanes that are in a walk take one; while a fair number is still walking
+      // the round goes on with them (most walks end after two orders)
+      for (;;) {
+        bool walking = state == kTsWalk && !finish && !ended;
+        if (walking) {
+          const float alpha = sf.roughness * sf.roughness;
+          const float iorOut = sf.outside ? 1.0f : sf.ior;
+          const float iorIn = sf.outside ? sf.ior : 1.0f;
+          if (heitz_walk_step(p.rng, walk, sf.interaction, sf.baseLinear, alpha, iorOut, iorIn)) {
+            weight = heitz_walk_result(walk, sf.interaction, sf.baseLinear, lightDir);
+            finish = true;
+            walking = false;
+          }
         }
+        if (__popcll(__ballot(walking)) < LPT_WALK_STAY) break;
       }
       if (finish) {
         if (shade_end(p, sf, weight, lightDir, bounce, maxBounces, sample)) {
