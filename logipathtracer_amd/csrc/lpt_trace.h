@@ -20,11 +20,16 @@
 namespace lpt {
 
 #ifndef LPT_SURFACE_THRESHOLD
-#define LPT_SURFACE_THRESHOLD 32
+#define LPT_SURFACE_THRESHOLD 40
+#endif
+// New paths are started when at least this many lanes have none (or the wave has nothing else to do):
+// ray generation is costly and would otherwise run for a handful of lanes in every surface round.
+#ifndef LPT_NEW_MIN
+#define LPT_NEW_MIN 12
 #endif
 // A surface round repeats the walk order while at least this many lanes are still in a walk.
 #ifndef LPT_WALK_STAY
-#define LPT_WALK_STAY 12
+#define LPT_WALK_STAY 4
 #endif
 // Upper bound on the rounds of one wave, far above any real batch (a wave of a full-size batch
 // runs a few million): an exit every wave reaches even if a lane's state were corrupted.
@@ -177,7 +182,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
       // new paths for the lanes without one
       const unsigned long long bN = __ballot(state == kTsNew);
       const int nN = __popcll(bN);
-      if (nN > 0) {
+      const bool othersActive = __ballot(state != kTsNew && state != kTsDone) != 0ull;
+      if (nN > 0 && (nN >= LPT_NEW_MIN || !othersActive)) {
         LPT_STAT(4, nN);
         while (!exhausted && chunkNext >= chunkEnd) {
           const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
