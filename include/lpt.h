@@ -93,7 +93,8 @@ enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (fastest;
  *            128 bytes of queues per path in flight).
  * MEGAKERNEL: one thread per pixel runs the whole path (the shader's own organisation).
- * PERSISTENT: one launch per batch, paths stay in registers (16 bytes per path in flight). */
+ * PERSISTENT: one launch per batch, paths stay in registers (16 bytes per path in flight;
+ *             within a few per cent of WAVEFRONT). */
 enum { LPT_PIPELINE_WAVEFRONT = 0, LPT_PIPELINE_MEGAKERNEL = 1, LPT_PIPELINE_PERSISTENT = 2 };
 /* Mesh BVH builders offered by lpt_build_mesh_bvh. */
 enum { LPT_BVH_LBVH = 0 };
