@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_box.gltf"))
     ap.add_argument("--builder", type=int, default=0)
-    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 megakernel, 2 persistent, 3 automatic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0: automatic)")
     return ap.parse_args()
@@ -153,6 +153,7 @@ def main():
         ext_ms += st.extend_ms
         ext_launches += st.extend_launches
         dev_ms += st.device_ms
+        used_pipeline = st.pipeline
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -217,7 +218,8 @@ def main():
                             f"Heitz BSDF, {spp_step} spp per step ({args.spp_per_step} per GPU)",
                 "spp_per_step": spp_step, "tile": args.tile if world > 1 else None,
                 "builder": ["split_bvh", "binned_sah", "lbvh_gpu"][args.builder],
-                "pipeline": ["wavefront", "megakernel", "persistent"][args.pipeline],
+                "pipeline": ["wavefront", "megakernel", "persistent"][used_pipeline]
+                            + (" (chosen automatically)" if args.pipeline == 3 else ""),
             },
             "nominal_msamples_per_s": nominal / elapsed / 1e6,
             "traced_segments": seg_total,
@@ -248,7 +250,7 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
             default_workload = (os.path.basename(args.scene) == "cornell_box.gltf" and args.bounces == 8
-                                and args.pipeline == 0 and (args.width, args.height) == (1920, 1080))
+                                and used_pipeline == 0 and (args.width, args.height) == (1920, 1080))
             if os.path.exists(tpath) and default_workload:
                 try:
                     t = json.load(open(tpath))
@@ -257,7 +259,7 @@ def main():
                     traffic = None
             avg_s = ext_ms * 1e-3 / max(ext_launches, 1)
             result["roofline"] = {
-                "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": "k_extend" if used_pipeline == 0 else ("k_trace" if used_pipeline == 2 else "k_megakernel"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "hbm_measured_gbs": (traffic / avg_s / 1e9) if traffic else None,
                 "note": "achieved = algorithmic bytes (48 B/node fetched + 36 B/triangle + 36 B ray/hit) x segments / "

@@ -89,13 +89,15 @@ typedef enum lpt_status {
 
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
-/* Kernel organisation; all three produce identical pixels.
+/* Kernel organisation; all produce identical pixels.
+ * AUTO (default): WAVEFRONT for batches of about 100 Mi paths and more whose queues fit in
+ *            device memory, PERSISTENT otherwise (single frames, interactive use).
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (fastest;
  *            128 bytes of queues per path in flight).
  * MEGAKERNEL: one thread per pixel runs the whole path (the shader's own organisation).
  * PERSISTENT: one launch per batch, paths stay in registers (16 bytes per path in flight;
  *             within a few per cent of WAVEFRONT). */
-enum { LPT_PIPELINE_WAVEFRONT = 0, LPT_PIPELINE_MEGAKERNEL = 1, LPT_PIPELINE_PERSISTENT = 2 };
+enum { LPT_PIPELINE_WAVEFRONT = 0, LPT_PIPELINE_MEGAKERNEL = 1, LPT_PIPELINE_PERSISTENT = 2, LPT_PIPELINE_AUTO = 3 };
 /* Mesh BVH builders offered by lpt_build_mesh_bvh. */
 enum { LPT_BVH_LBVH = 0 };
 
@@ -109,7 +111,7 @@ typedef struct lpt_stats {
   double   device_ms;     /* HIP-event time of the whole call on the context's stream */
   double   extend_ms;     /* summed HIP-event time of the traversal kernel launches */
   uint32_t extend_launches;
-  uint32_t pad;
+  uint32_t pipeline;      /* organisation the call ran with (what LPT_PIPELINE_AUTO resolved to) */
 } lpt_stats;
 
 /* ---- context ---------------------------------------------------------------- */

@@ -6,7 +6,7 @@ import numpy as np
 from . import _native as N
 
 BSDF_HEITZ, BSDF_BASIC = 0, 1
-PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_PERSISTENT = 0, 1, 2
+PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_PERSISTENT, PIPELINE_AUTO = 0, 1, 2, 3
 BUILDER_SPLIT_BVH, BUILDER_BINNED_SAH, BUILDER_LBVH = 0, 1, 2
 
 
@@ -155,7 +155,7 @@ class Device:
     def set_partition(self, tile_w, tile_h, rank, n_ranks):
         self._check(N.hip.lpt_set_partition(self._ctx, tile_w, tile_h, rank, n_ranks))
 
-    def set_options(self, max_bounces=10, bsdf_mode=BSDF_HEITZ, pipeline=PIPELINE_WAVEFRONT, frames_in_flight=0):
+    def set_options(self, max_bounces=10, bsdf_mode=BSDF_HEITZ, pipeline=PIPELINE_AUTO, frames_in_flight=0):
         self._check(N.hip.lpt_set_options(self._ctx, max_bounces, bsdf_mode, pipeline, frames_in_flight))
 
     def render_frames(self, ubos):
@@ -248,7 +248,7 @@ class Renderer:
     def load_scene(self, gltf_path, builder=BUILDER_SPLIT_BVH):
         self._check(N.host.lpth_renderer_load_gltf(self._h, str(gltf_path).encode(), builder))
 
-    def configure(self, seed=0x5EED, max_bounces=10, bsdf_mode=BSDF_HEITZ, pipeline=PIPELINE_WAVEFRONT,
+    def configure(self, seed=0x5EED, max_bounces=10, bsdf_mode=BSDF_HEITZ, pipeline=PIPELINE_AUTO,
                   frames_in_flight=0):
         self._check(N.host.lpth_renderer_configure(self._h, seed, max_bounces, bsdf_mode, pipeline, frames_in_flight))
 

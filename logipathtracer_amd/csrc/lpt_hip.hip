@@ -440,7 +440,8 @@ struct lpt_ctx {
   // options
   int maxBounces = 10;  // MAX_TRACE_DEPTH, shaders/path_tracing.comp:20
   int bsdfMode = LPT_BSDF_HEITZ;
-  int pipeline = LPT_PIPELINE_WAVEFRONT;
+  int pipeline = LPT_PIPELINE_AUTO;
+  int activePipeline = LPT_PIPELINE_WAVEFRONT;  // what AUTO resolved to for the current call
   int framesInFlight = 0;
   int extendBlocksPerCU = 8;
 
@@ -620,7 +621,7 @@ int auto_frames_in_flight(const lpt_ctx* c) {
 int ensure_pool(lpt_ctx* c, int frames) {
   size_t paths = (size_t)frames * c->part.nSlots;
   // wavefront: 2 queues x 3 arrays + hits + samples = 8 float4 arrays; persistent: samples only
-  const int arrays = c->pipeline == LPT_PIPELINE_PERSISTENT ? 1 : 8;
+  const int arrays = c->activePipeline == LPT_PIPELINE_PERSISTENT ? 1 : 8;
   if (paths > c->poolPaths || arrays != c->poolArrays) {
     dfree(c->dPool);
     c->poolPaths = 0;
@@ -1192,7 +1193,8 @@ int lpt_set_options(lpt_ctx* c, int max_bounces, int bsdf_mode, int pipeline, in
   if (!c) return LPT_ERR_INVALID;
   if (max_bounces < 1 || max_bounces > 4096) return fail(c, LPT_ERR_INVALID, "max_bounces out of range");
   if (bsdf_mode != LPT_BSDF_HEITZ && bsdf_mode != LPT_BSDF_BASIC) return fail(c, LPT_ERR_INVALID, "bad bsdf_mode");
-  if (pipeline != LPT_PIPELINE_WAVEFRONT && pipeline != LPT_PIPELINE_MEGAKERNEL && pipeline != LPT_PIPELINE_PERSISTENT)
+  if (pipeline != LPT_PIPELINE_WAVEFRONT && pipeline != LPT_PIPELINE_MEGAKERNEL && pipeline != LPT_PIPELINE_PERSISTENT &&
+      pipeline != LPT_PIPELINE_AUTO)
     return fail(c, LPT_ERR_INVALID, "bad pipeline");
   if (frames_in_flight < 0 || frames_in_flight > 4096) return fail(c, LPT_ERR_INVALID, "bad frames_in_flight");
   c->maxBounces = max_bounces;
@@ -1214,6 +1216,7 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, 16 * sizeof(unsigned long long), c->stream));
   LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
   if (c->pipeline == LPT_PIPELINE_MEGAKERNEL) {
+    c->activePipeline = LPT_PIPELINE_MEGAKERNEL;
     for (int f = 0; f < n_frames; ++f) {
       rc = render_frame_mega(c, ubos[f]);
       if (rc) return rc;
@@ -1223,12 +1226,26 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     int fif = std::min(auto_frames_in_flight(c), n_frames);
     // path ids of a batch must leave bit 31 free (kAccStored)
     fif = std::max(1, std::min<int>(fif, (int)(0x7FFFFFFFu / std::max<uint32_t>(c->part.nSlots, 1u))));
-    while ((rc = ensure_pool(c, fif)) == LPT_ERR_NOMEM && fif > 1) fif = (fif + 1) / 2;
+    // AUTO: the wavefront kernels are faster once a batch is large enough to hide the latency-bound
+    // tail that each of their launches ends in (measured on MI355X: from about 100 Mi paths); below
+    // that, and when the ray queues do not fit, the single persistent launch wins.
+    c->activePipeline = c->pipeline;
+    if (c->pipeline == LPT_PIPELINE_AUTO)
+      c->activePipeline = (double)fif * c->part.nSlots >= 96.0 * 1024 * 1024 ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_PERSISTENT;
+    rc = ensure_pool(c, fif);
+    if (rc == LPT_ERR_NOMEM && c->pipeline == LPT_PIPELINE_AUTO && c->activePipeline == LPT_PIPELINE_WAVEFRONT) {
+      c->activePipeline = LPT_PIPELINE_PERSISTENT;
+      rc = ensure_pool(c, fif);
+    }
+    while (rc == LPT_ERR_NOMEM && fif > 1) {
+      fif = (fif + 1) / 2;
+      rc = ensure_pool(c, fif);
+    }
     if (rc) return rc;
     for (int f = 0; f < n_frames; f += fif) {
       int nb = std::min(fif, n_frames - f);
       if (f > 0) LPT_HIP(c, hipStreamSynchronize(c->stream));  // pinned ubo staging is reused
-      rc = c->pipeline == LPT_PIPELINE_PERSISTENT ? render_batch_persistent(c, ubos + f, nb)
+      rc = c->activePipeline == LPT_PIPELINE_PERSISTENT ? render_batch_persistent(c, ubos + f, nb)
                                                    : render_batch_wavefront(c, ubos + f, nb);
       if (rc) return rc;
     }
@@ -1287,6 +1304,7 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   }
   out->extend_ms = ext;
   out->extend_launches = (uint32_t)(c->evUsed / 2);
+  out->pipeline = (uint32_t)c->activePipeline;
   return LPT_OK;
 }
 

@@ -42,7 +42,7 @@ static void writePPM(const std::string& path, const std::vector<float>& rgba, in
 
 int main(int argc, char** argv) {
   std::string scenePath, out = "render";
-  int width = 1920, height = 1080, spp = 64, bounces = 10, device = 0, bsdf = 0, pipeline = 0, builder = 0;
+  int width = 1920, height = 1080, spp = 64, bounces = 10, device = 0, bsdf = 0, pipeline = LPT_PIPELINE_AUTO, builder = 0;
   uint32_t seed = 0x5EED;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -54,6 +54,7 @@ int main(int argc, char** argv) {
     else if (a == "--seed") seed = (uint32_t)std::strtoul(next(), nullptr, 0);
     else if (a == "--device") device = std::atoi(next());
     else if (a == "--basic-bsdf") bsdf = 1;
+    else if (a == "--wavefront") pipeline = 0;
     else if (a == "--megakernel") pipeline = 1;
     else if (a == "--persistent") pipeline = 2;
     else if (a == "--builder") builder = std::atoi(next());
@@ -62,7 +63,7 @@ int main(int argc, char** argv) {
     else { std::cerr << "unknown option " << a << "\n"; return 2; }
   }
   if (scenePath.empty()) {
-    std::cerr << "usage: lpt_render scene.gltf [--width W --height H --spp N --bounces B --seed S --device D --basic-bsdf --megakernel | --persistent --builder 0|1|2 --out prefix]\n";
+    std::cerr << "usage: lpt_render scene.gltf [--width W --height H --spp N --bounces B --seed S --device D --basic-bsdf --wavefront | --megakernel | --persistent --builder 0|1|2 --out prefix]\n";
     return 2;
   }
   try {

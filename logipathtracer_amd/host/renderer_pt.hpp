@@ -62,7 +62,7 @@ class RendererPT : public RendererCore {
 
   int maxTraceDepth_ = 10;
   int bsdfMode_ = LPT_BSDF_HEITZ;
-  int pipeline_ = LPT_PIPELINE_WAVEFRONT;
+  int pipeline_ = LPT_PIPELINE_AUTO;
   int framesInFlight_ = 0;
   bool verbose_ = false;
   bool batching_ = false;
