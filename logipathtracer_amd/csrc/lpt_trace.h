@@ -31,10 +31,11 @@ namespace lpt {
 #ifndef LPT_WALK_STAY
 #define LPT_WALK_STAY 4
 #endif
-// Upper bound on the rounds of one wave, far above any real batch (a wave of a full-size batch
-// runs a few million): an exit every wave reaches even if a lane's state were corrupted.
+// Upper bound on the rounds of one wave, far above any real batch (a wave of the largest batch,
+// 256 Mi paths, runs a few hundred thousand): an exit every wave reaches within seconds even if
+// a lane's state were corrupted.
 #ifndef LPT_TRACE_ROUND_LIMIT
-#define LPT_TRACE_ROUND_LIMIT (1u << 28)
+#define LPT_TRACE_ROUND_LIMIT (1u << 24)
 #endif
 constexpr int kTsNew = 0, kTsInner = 1, kTsTri = 2, kTsObj = 3, kTsShade = 4, kTsWalk = 5, kTsDone = 6;
 
