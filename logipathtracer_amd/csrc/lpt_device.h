@@ -152,16 +152,20 @@ __device__ __forceinline__ void box_test_pair(f3 o, f3 inv, float4 q0, float4 q1
   const v2f ix{inv.x, inv.x}, iy{inv.y, inv.y}, iz{inv.z, inv.z};
   const v2f nx = (v2f{q0.x, q0.y} - ox) * ix, ny = (v2f{q0.z, q0.w} - oy) * iy, nz = (v2f{q1.x, q1.y} - oz) * iz;
   const v2f fx = (v2f{q1.z, q1.w} - ox) * ix, fy = (v2f{q2.x, q2.y} - oy) * iy, fz = (v2f{q2.z, q2.w} - oz) * iz;
-  {
-    float t0 = max_num(max_num(min_num(nx.x, fx.x), min_num(ny.x, fy.x)), min_num(nz.x, fz.x));
-    float t1 = min_num(min_num(max_num(nx.x, fx.x), max_num(ny.x, fy.x)), max_num(nz.x, fz.x));
-    h0 = !(t0 > t1) && ((t0 > 0.0f) ? (t0 < dist) : (t1 > 0.0f));
-  }
-  {
-    float t0 = max_num(max_num(min_num(nx.y, fx.y), min_num(ny.y, fy.y)), min_num(nz.y, fz.y));
-    float t1 = min_num(min_num(max_num(nx.y, fx.y), max_num(ny.y, fy.y)), max_num(nz.y, fz.y));
-    h1 = !(t0 > t1) && ((t0 > 0.0f) ? (t0 < dist) : (t1 > 0.0f));
-  }
+  // min/max element-wise on the pairs
+  const v2f lo = __builtin_elementwise_max(
+      __builtin_elementwise_max(__builtin_elementwise_min(nx, fx), __builtin_elementwise_min(ny, fy)),
+      __builtin_elementwise_min(nz, fz));
+  const v2f hi = __builtin_elementwise_min(
+      __builtin_elementwise_min(__builtin_elementwise_max(nx, fx), __builtin_elementwise_max(ny, fy)),
+      __builtin_elementwise_max(nz, fz));
+  // The decision  !(t0 > t1) && (t0 > 0 ? t0 < dist : t1 > 0)  in three comparisons, given that the
+  // caller's dist is a positive number (a hit distance above kEps, or kInfinity):
+  //  - t0 > 0 with t0 <= t1 implies t1 > 0, and t0 <= 0 implies t0 < dist, so each arm of the
+  //    conditional equals (t1 > 0) && (t0 < dist);
+  //  - t0 is NaN exactly when t1 is (both only when all three axes gave NaN), and then both forms are false.
+  h0 = !(lo.x > hi.x) & (hi.x > 0.0f) & (lo.x < dist);
+  h1 = !(lo.y > hi.y) & (hi.y > 0.0f) & (lo.y < dist);
 }
 
 // shaders/common/ray.glsl:63-82 (Moeller-Trumbore, no culling, no parallel check)
