@@ -8,8 +8,10 @@ CSRC    := logipathtracer_amd/csrc
 HOST    := logipathtracer_amd/host
 
 # Bit-level parity with the CPU oracle needs: no FMA contraction, IEEE divide/sqrt, no fast-math.
+# No SLP vectorisation: packing scalar f32 arithmetic into v_pk_* costs more v_mov shuffles than it
+# saves (measured: 11 % on the persistent kernel); the one place where pairs pay is written by hand.
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(HIPFLAGS_EXTRA) -ffp-contract=off \
-            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-pass-failed
+            -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra
 
 HOST_SRCS := $(HOST)/lsg_min.cpp $(HOST)/png_decode.cpp $(HOST)/lsg_bvh.cpp $(HOST)/pt_scene_converter.cpp \
