@@ -141,21 +141,20 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     } else if (nI >= nT && nI >= nO) {
       LPT_XSTAT(1, nI);
       if (state == kStInner) {
-        bool mine = true;
         for (;;) {
-          if (mine) {
-            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            bool h0, h1;
-            box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
-            const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-            if (h0 && h1) stk[(sp++) * BLOCK] = r0;
-            cur = h1 ? r1 : r0;
-            if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
-            mine = cur < kRefMarker;  // still an inner node (marker, leaves and the sentinel are larger)
-          }
-          const int left = __popcll(__ballot(mine));
-          if (left == 0 || LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
+          const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+          const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+          bool h0, h1;
+          box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+          const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+          if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+          cur = h1 ? r1 : r0;
+          if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
+          // a lane leaves the burst when its next reference is no inner node (the marker, leaves and
+          // the sentinel are larger); the others go on while they are enough of those that entered
+          if (cur >= kRefMarker) break;
+          const int left = __popcll(__ballot(1));
+          if (LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
           LPT_XSTAT(4, left);
         }
         stepped = true;  // `cur` already holds the next reference
@@ -163,8 +162,8 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     } else if (nT >= nO) {
       LPT_XSTAT(2, nT);
       if (state == kStTri) {
-        for (int it = 1;; ++it) {
-          if (triI < triEnd) {
+        if (triI < triEnd)
+          for (int it = 1;; ++it) {
             const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
             const float4 a = tq[0], b = tq[1], c = tq[2];
             const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
@@ -173,12 +172,11 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
               hit.obj = curObj;
               hit.prim = as_uint(a.w);
             }
-            ++triI;
+            if (++triI >= triEnd) break;  // leaf done: this lane leaves the burst
+            const int left = __popcll(__ballot(1));
+            if (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT) break;
+            LPT_XSTAT(5, left);
           }
-          const int left = __popcll(__ballot(triI < triEnd));
-          if (left) LPT_XSTAT(5, left);
-          if (left == 0 || (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT)) break;
-        }
         if (triI >= triEnd) {
           needPop = true;
           stepped = true;

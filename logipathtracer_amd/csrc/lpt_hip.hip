@@ -1289,6 +1289,9 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
     for (int k = 0; k < 5; ++k)
       std::fprintf(stderr, "trace rounds %-8s %12llu  lanes/round %.1f\n", names[k], t[2 + 2 * k],
                    t[2 + 2 * k] ? (double)t[3 + 2 * k] / (double)t[2 + 2 * k] : 0.0);
+    const double all = (double)(t[12] + t[13] + t[14] + t[15]);
+    for (int k = 0; k < 4; ++k)
+      std::fprintf(stderr, "trace wave time %-8s %5.1f %%\n", names[k], all > 0 ? 100.0 * (double)t[12 + k] / all : 0.0);
   }
 #endif
   out->paths = totals[0];

@@ -84,11 +84,22 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
 #ifdef LPT_TRACE_STATS
   uint32_t stRounds[5] = {0, 0, 0, 0, 0};
   uint32_t stLanes[5] = {0, 0, 0, 0, 0};
-#define LPT_STAT(k, lanes) (++stRounds[k], stLanes[k] += (uint32_t)(lanes))
+  // wave time per kind of round (0 inner, 1 tri, 2 obj, 3 surface incl. new paths), in clock64 ticks
+  unsigned long long stTicks[4] = {0, 0, 0, 0};
+  long long stT0 = clock64();
+  int stKind = 3;
+#define LPT_STAT(k, lanes) (++stRounds[k], stLanes[k] += (uint32_t)(lanes), stKind = (k) > 3 ? 3 : (k))
 #else
 #define LPT_STAT(k, lanes) ((void)0)
 #endif
   for (uint32_t round = 0; round < LPT_TRACE_ROUND_LIMIT; ++round) {
+#ifdef LPT_TRACE_STATS
+    {
+      const long long now = clock64();
+      stTicks[stKind] += (unsigned long long)(now - stT0);
+      stT0 = now;
+    }
+#endif
     const unsigned long long bI = __ballot(state == kTsInner);
     const unsigned long long bT = __ballot(state == kTsTri);
     const unsigned long long bO = __ballot(state == kTsObj);
@@ -253,29 +264,26 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     if (nI >= nT && nI >= nO) {
       LPT_STAT(0, nI);
       if (state == kTsInner) {  // burst over consecutive inner nodes, as in k_extend
-        bool mine = true;
         for (;;) {
-          if (mine) {
-            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            bool h0, h1;
-            box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
-            const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-            if (h0 && h1) stk[(sp++) * BLOCK] = r0;
-            cur = h1 ? r1 : r0;
-            if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
-            mine = cur < kRefMarker;
-          }
-          const int left = __popcll(__ballot(mine));
-          if (left == 0 || LPT_BURST_INNER_DEN * left < LPT_BURST_INNER_NUM * nI) break;
+          const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+          const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+          bool h0, h1;
+          box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+          const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
+          if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+          cur = h1 ? r1 : r0;
+          if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
+          if (cur >= kRefMarker) break;  // no longer an inner node: this lane leaves the burst
+          // the lanes still here go on while they are enough of those that entered
+          if (LPT_BURST_INNER_DEN * __popcll(__ballot(1)) < LPT_BURST_INNER_NUM * nI) break;
         }
         stepped = true;  // `cur` already holds the next reference
       }
     } else if (nT >= nO) {
       LPT_STAT(1, nT);
       if (state == kTsTri) {
-        for (int it = 1;; ++it) {  // the whole leaf, as in k_extend
-          if (triI < triEnd) {
+        if (triI < triEnd)
+          for (int it = 1;; ++it) {  // the whole leaf, as in k_extend
             const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
             const float4 a = tq[0], b = tq[1], c = tq[2];
             const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
@@ -284,11 +292,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
               hit.obj = curObj;
               hit.prim = as_uint(a.w);
             }
-            ++triI;
+            if (++triI >= triEnd) break;  // leaf done: this lane leaves the burst
+            if (it >= kBurstTriFree && LPT_BURST_TRI_DEN * __popcll(__ballot(1)) < LPT_BURST_TRI_NUM * nT) break;
           }
-          const int left = __popcll(__ballot(triI < triEnd));
-          if (left == 0 || (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT)) break;
-        }
         if (triI >= triEnd) {
           needPop = true;
           stepped = true;
@@ -372,6 +378,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     for (int k = 0; k < 5; ++k) {
       atomicAdd(&totals[2 + 2 * k], (unsigned long long)stRounds[k]);
       atomicAdd(&totals[3 + 2 * k], (unsigned long long)stLanes[k]);
+      if (k < 4) atomicAdd(&totals[12 + k], stTicks[k]);
     }
 #endif
 }
