@@ -110,6 +110,14 @@ struct DScene {
   uint32_t nNodes, nTris, nObjects;
 };
 
+// Address of record `index` as 16-byte words.  Every array here is far below 4 GiB (references
+// carry 25-bit indices), so the byte offset is formed in 32 bits: one vector instruction and the
+// addressing form "uniform base + 32-bit lane offset" instead of 64-bit multiply-adds.
+template <class T>
+__device__ __forceinline__ const float4* record_words(const T* base, uint32_t index) {
+  return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + index * (uint32_t)sizeof(T));
+}
+
 struct Hit {
   float t;
   uint32_t obj;

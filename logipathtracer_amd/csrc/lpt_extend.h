@@ -142,7 +142,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       LPT_XSTAT(1, nI);
       if (state == kStInner) {
         for (;;) {
-          const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+          const float4* q = record_words(sc.nodes, cur);
           const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
           bool h0, h1;
           box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
@@ -164,7 +164,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       if (state == kStTri) {
         if (triI < triEnd)
           for (int it = 1;; ++it) {
-            const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
+            const float4* tq = record_words(sc.tris, triI);
             const float4 a = tq[0], b = tq[1], c = tq[2];
             const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
             if (td > kEps && td < hit.t) {
@@ -192,7 +192,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         } else {
           if (count > 1u) stk[(sp++) * BLOCK] = make_leaf_ref(first + 1u, count - 1u);
           stk[(sp++) * BLOCK] = kRefMarker;
-          const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
+          const float4* oq = record_words(sc.otrav, first);
           const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
           co = xform_point(rows, wo);

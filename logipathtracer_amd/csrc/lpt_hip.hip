@@ -1226,12 +1226,19 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     int fif = std::min(auto_frames_in_flight(c), n_frames);
     // path ids of a batch must leave bit 31 free (kAccStored)
     fif = std::max(1, std::min<int>(fif, (int)(0x7FFFFFFFu / std::max<uint32_t>(c->part.nSlots, 1u))));
-    // AUTO: the wavefront kernels are faster once a batch is large enough to hide the latency-bound
-    // tail that each of their launches ends in (measured on MI355X: from about 100 Mi paths); below
-    // that, and when the ray queues do not fit, the single persistent launch wins.
+    // AUTO: the persistent launch, unless the scene is large and the batch too.  The persistent kernel
+    // keeps four waves per SIMD, enough while the tree and the triangles stay in an XCD's 4 MiB L2
+    // (Cornell box: 11 % ahead of the wavefront kernels at 128 Mi paths, 3.4x at 2 Mi).  On a scene
+    // that does not, the wavefront kernels' seven waves hide the longer loads better, provided a
+    // batch is large enough to amortise the tail each of their launches ends in (from about 100 Mi
+    // paths) and the ray queues fit.
     c->activePipeline = c->pipeline;
-    if (c->pipeline == LPT_PIPELINE_AUTO)
-      c->activePipeline = (double)fif * c->part.nSlots >= 96.0 * 1024 * 1024 ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_PERSISTENT;
+    if (c->pipeline == LPT_PIPELINE_AUTO) {
+      const double traversalBytes = 64.0 * c->nNodes + 48.0 * c->nTris;
+      const bool largeScene = traversalBytes > 4.0 * 1024 * 1024;
+      const bool largeBatch = (double)fif * c->part.nSlots >= 96.0 * 1024 * 1024;
+      c->activePipeline = largeScene && largeBatch ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_PERSISTENT;
+    }
     rc = ensure_pool(c, fif);
     if (rc == LPT_ERR_NOMEM && c->pipeline == LPT_PIPELINE_AUTO && c->activePipeline == LPT_PIPELINE_WAVEFRONT) {
       c->activePipeline = LPT_PIPELINE_PERSISTENT;

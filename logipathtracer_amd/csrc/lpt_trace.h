@@ -265,7 +265,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
       LPT_STAT(0, nI);
       if (state == kTsInner) {  // burst over consecutive inner nodes, as in k_extend
         for (;;) {
-          const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+          const float4* q = record_words(sc.nodes, cur);
           const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
           bool h0, h1;
           box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
@@ -282,10 +282,17 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     } else if (nT >= nO) {
       LPT_STAT(1, nT);
       if (state == kTsTri) {
-        if (triI < triEnd)
-          for (int it = 1;; ++it) {  // the whole leaf, as in k_extend
-            const float4* tq = reinterpret_cast<const float4*>(sc.tris + triI);
-            const float4 a = tq[0], b = tq[1], c = tq[2];
+        if (triI < triEnd) {
+          // the whole leaf, as in k_extend; the next triangle is loaded while the current one is tested
+          const float4* tq = record_words(sc.tris, triI);
+          float4 a = tq[0], b = tq[1], c = tq[2];
+          for (int it = 1;; ++it) {
+            float4 na = a, nb = b, nc = c;
+            if (triI + 1u < triEnd) {
+              na = tq[3];
+              nb = tq[4];
+              nc = tq[5];
+            }
             const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
             if (td > kEps && td < hit.t) {
               hit.t = td;
@@ -294,7 +301,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
             }
             if (++triI >= triEnd) break;  // leaf done: this lane leaves the burst
             if (it >= kBurstTriFree && LPT_BURST_TRI_DEN * __popcll(__ballot(1)) < LPT_BURST_TRI_NUM * nT) break;
+            tq += 3;
+            a = na;
+            b = nb;
+            c = nc;
           }
+        }
         if (triI >= triEnd) {
           needPop = true;
           stepped = true;
@@ -313,7 +325,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
         } else {
           if (count > 1u) stk[(sp++) * BLOCK] = make_leaf_ref(first + 1u, count - 1u);
           stk[(sp++) * BLOCK] = kRefMarker;
-          const float4* oq = reinterpret_cast<const float4*>(sc.otrav + first);
+          const float4* oq = record_words(sc.otrav, first);
           const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
           co = xform_point(rows, p.o);
