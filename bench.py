@@ -237,20 +237,32 @@ def main():
         else:
             counters = traversal_counters(scene, ubos, args.width, args.height, args.bounces)
         result["cpu_baseline"] = cpu
-        # roofline of the dominant kernel (k_extend): algorithmic bytes per traced segment =
-        # 64 B per inner node visited (both child boxes) ... stated in interchange terms as
-        # 48 B per node fetched + 36 B per triangle tested + 24 B ray in + 12 B hit out.
+        # Roofline of the dominant kernel.  Algorithmic bytes per traced segment, in interchange terms:
+        # 48 B per node fetched + 36 B per triangle tested, plus
+        #   k_extend (wavefront):  24 B ray in + 12 B hit out;
+        #   k_trace (persistent):  per hit the object record and three vertices (208 + 144 B), per path
+        #                          the 16 B radiance sample (paths live in registers: no queue traffic).
         if counters and ext_ms > 0:
             n_node = (counters["boxTests"] + counters["rootVisits"]) / counters["segments"]
             n_tri = counters["triTests"] / counters["segments"]
-            bytes_per_seg = 48.0 * n_node + 36.0 * n_tri + 24.0 + 12.0
+            p_hit = counters["hits"] / counters["segments"]
+            mean_len = counters["segments"] / max(counters["paths"], 1)
+            kernel = "k_extend" if used_pipeline == 0 else ("k_trace" if used_pipeline == 2 else "k_megakernel")
+            if kernel == "k_extend":
+                state_bytes = 24.0 + 12.0
+                state_note = "36 B ray/hit"
+            else:
+                state_bytes = p_hit * (208.0 + 144.0) + 16.0 / mean_len
+                state_note = "352 B object+vertices per hit + 16 B sample per path"
+            bytes_per_seg = 48.0 * n_node + 36.0 * n_tri + state_bytes
             achieved = bytes_per_seg * float(seg) / (ext_ms * 1e-3) / 1e9
-            # HBM bytes per launch: PMC measurement of this workload (profiles/extend_traffic.json holds bytes
+            # HBM bytes per launch: PMC measurement of this workload (profiles/*_traffic.json holds bytes
             # and segments per launch of the profiled run), scaled to this run's segments per launch
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", {"k_extend": "extend_traffic.json", "k_trace": "trace_traffic.json"}
+                                 .get(kernel, "none"))
             default_workload = (os.path.basename(args.scene) == "cornell_box.gltf" and args.bounces == 8
-                                and used_pipeline == 0 and (args.width, args.height) == (1920, 1080))
+                                and (args.width, args.height) == (1920, 1080))
             if os.path.exists(tpath) and default_workload:
                 try:
                     t = json.load(open(tpath))
@@ -259,12 +271,14 @@ def main():
                     traffic = None
             avg_s = ext_ms * 1e-3 / max(ext_launches, 1)
             result["roofline"] = {
-                "kernel": "k_extend" if used_pipeline == 0 else ("k_trace" if used_pipeline == 2 else "k_megakernel"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "hbm_measured_gbs": (traffic / avg_s / 1e9) if traffic else None,
-                "note": "achieved = algorithmic bytes (48 B/node fetched + 36 B/triangle + 36 B ray/hit) x segments / "
-                        "k_extend time; the scene is cache-resident, so measured HBM traffic is far lower",
+                "note": f"achieved = algorithmic bytes (48 B/node fetched + 36 B/triangle + {state_note}) x segments / "
+                        f"{kernel} time; the scene is cache-resident, so measured HBM traffic is far lower and the "
+                        "kernel is bound by the L1 gather path and vector issue, not by HBM",
                 "bytes_per_segment": bytes_per_seg, "nodes_per_segment": n_node, "tris_per_segment": n_tri,
+                "hits_per_segment": p_hit,
                 "avg_launch_ms": ext_ms / max(ext_launches, 1), "launches": ext_launches,
                 "segments_per_launch": float(seg) / max(ext_launches, 1),
             }

@@ -3,7 +3,8 @@
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the bench command
   profiles/<tag>_pmc.txt            per-kernel PMC totals and derived ratios
-  profiles/extend_traffic.json      HBM bytes per k_extend launch, read by bench.py (roofline.traffic)
+  profiles/trace_traffic.json, extend_traffic.json   HBM bytes per k_trace / k_extend launch, read by
+                                    bench.py (roofline.traffic)
 
 HBM bytes follow the gfx950 rule for rocprofv3: FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE counts
 128-byte read requests as 64 bytes, so reads are doubled: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -48,23 +49,28 @@ def per_dispatch(counter, kernel_substr):
     return (tot / n if n else None), n
 
 
-fetch, nf = per_dispatch("FETCH_SIZE", "k_extend")
-write, nw = per_dispatch("WRITE_SIZE", "k_extend")
-segs = None
-try:
-    b = json.load(open(os.path.join(src, "fetch.json")))
-    segs = b["traced_segments"] / b["extend_launches_rank0"]
-except Exception:
-    pass
-if fetch is not None and write is not None:
+# HBM bytes per launch of the kernel that dominates the profiled run (k_trace: persistent pipeline,
+# k_extend: wavefront pipeline); bench.py reads the file of the kernel it ran for roofline.traffic
+for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_traffic.json")):
+    fetch, nf = per_dispatch("FETCH_SIZE", kernel)
+    write, nw = per_dispatch("WRITE_SIZE", kernel)
+    if fetch is None or write is None:
+        continue
+    segs = None
+    try:
+        b = json.load(open(os.path.join(src, "fetch.json")))
+        segs = b["traced_segments"] / b["extend_launches_rank0"]
+    except Exception:
+        pass
     traffic = {
-        "kernel": "k_extend",
-        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+        "kernel": kernel,
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+                   + (" --pipeline 0" if kernel == "k_extend" else ""),
         "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write, "launches": nf,
         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
         "segments_per_launch": segs,
         "rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B reads as 64 B)",
     }
-    json.dump(traffic, open(os.path.join(dst, "extend_traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(dst, fname), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 print(buf.getvalue()[:3000])

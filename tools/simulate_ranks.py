@@ -15,7 +15,7 @@ for n in (1, 2, 4, 8):
         dev.resize(1920, 1080)
         if n > 1:
             dev.set_partition(64, 64, r, n)
-        dev.set_options(8, L.BSDF_HEITZ, L.PIPELINE_WAVEFRONT, 0)
+        dev.set_options(8, L.BSDF_HEITZ, L.PIPELINE_AUTO, 0)
         ubos = L.frame_ubos(scene.camera_world, scene.fov_y, 64 * n * 3)
         dev.render_frames(ubos[:64 * n])
         dev.synchronize()
