@@ -17,9 +17,12 @@
 // Rays are handed out in chunks: one atomic on a global cursor per chunk and wave, the
 // chunk is then consumed lane by lane as rays finish (no idle tail inside a wave).
 //
-// The scene is read from global memory: its hot part sits in L1/L2 and the kernel is bound by
-// vector-ALU issue, so LDS copies of the hottest nodes, triangles and object records (tried
-// from 16 nodes per workgroup to 768 nodes + 512 triangles) were no faster.
+// The scene is read from global memory.  Each step gathers one 64-byte node, 48-byte triangle or
+// 64-byte object record per lane at unrelated addresses; the L1 serves such loads lane by lane and
+// that, together with vector issue, is what bounds the kernel (not HBM: the hot part of the scene
+// sits in L1/L2).  LDS copies of the hottest nodes, triangles and object records (tried from 16
+// nodes per workgroup to 768 nodes + 512 triangles) were no faster: random 16-byte reads cost the
+// LDS what they cost the L1.
 #pragma once
 #include "lpt_device.h"
 
