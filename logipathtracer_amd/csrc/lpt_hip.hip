@@ -24,6 +24,7 @@
 #include "lpt_device.h"
 #include "lpt_extend.h"
 #include "lpt_trace.h"
+#include "lpt_primary.h"
 #include "lpt_internal.h"
 
 #pragma clang fp contract(off)
@@ -111,6 +112,15 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __re
                                                    float4* __restrict__ hits, uint32_t* cursor) {
   __shared__ uint32_t stack[S * kBlock];
   extend_persistent<S, kBlock>(sc, qo, qd, *count, hits, cursor, stack);
+}
+
+// Closest hit for the queued camera rays, 64 consecutive rays (one pixel block) per wave walked as a
+// packet with wave-uniform record loads.  See lpt_primary.h.
+__global__ __launch_bounds__(kBlock) void k_primary(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
+                                                    const ObjTrav* __restrict__ otrav, uint32_t rootRef,
+                                                    const float4* __restrict__ qo, const float4* __restrict__ qd,
+                                                    uint32_t count, float4* __restrict__ hits) {
+  primary_packet(nodes, tris, otrav, rootRef, qo, qd, count, hits);
 }
 
 // Shades queue entry i (a ray that hit something), samples the next direction, applies Russian
@@ -694,6 +704,20 @@ int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t*
   return launch_extend<64>(c, q, count, cursor, maxItems);
 }
 
+// Camera rays are traced as packets unless LPT_PRIMARY_PACKETS=0 (comparison runs).
+bool primary_packets() {
+  static const bool on = !(std::getenv("LPT_PRIMARY_PACKETS") && std::atoi(std::getenv("LPT_PRIMARY_PACKETS")) == 0);
+  return on;
+}
+
+// Closest hits of the `count` camera rays at the head of queue `q` (in path-id order) into c->dHits.
+void launch_primary(lpt_ctx* c, const Queue& q, uint32_t count) {
+  if (count == 0) return;
+  const DScene sc = device_scene(c);
+  hipLaunchKernelGGL(k_primary, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, sc.nodes, sc.tris, sc.otrav,
+                     sc.rootRef, q.o, q.d, count, c->dHits);
+}
+
 int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   int rc = ensure_pool(c, frames);
   if (rc) return rc;
@@ -715,7 +739,11 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-    dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
+    if (b == 0 && primary_packets()) {
+      launch_primary(c, in, (uint32_t)frames * c->nValid);
+    } else {
+      dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
+    }
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     static const int shadeResident = [] {
       int n = 0;
