@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "cornell_box.gltf"))
     ap.add_argument("--builder", type=int, default=0)
-    ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 megakernel, 2 persistent, 3 automatic")
+    ap.add_argument("--pipeline", type=int, default=3, help="0 wavefront, 1 megakernel, 2 persistent, 3 automatic, 4 hybrid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0: automatic)")
     return ap.parse_args()
@@ -218,7 +218,7 @@ def main():
                             f"Heitz BSDF, {spp_step} spp per step ({args.spp_per_step} per GPU)",
                 "spp_per_step": spp_step, "tile": args.tile if world > 1 else None,
                 "builder": ["split_bvh", "binned_sah", "lbvh_gpu"][args.builder],
-                "pipeline": ["wavefront", "megakernel", "persistent"][used_pipeline]
+                "pipeline": ["wavefront", "megakernel", "persistent", "auto", "hybrid"][used_pipeline]
                             + (" (chosen automatically)" if args.pipeline == 3 else ""),
             },
             "nominal_msamples_per_s": nominal / elapsed / 1e6,

@@ -90,15 +90,22 @@ typedef enum lpt_status {
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
 /* Kernel organisation; all produce identical pixels.
- * AUTO (default): PERSISTENT, except WAVEFRONT for a large scene (tree and triangles beyond an
- *            XCD's L2) rendered in batches of about 100 Mi paths and more whose queues fit in
- *            device memory.
+ * AUTO (default): HYBRID; WAVEFRONT for batches of about 100 Mi paths and more on a scene that
+ *            stays in cache; PERSISTENT when the ray queues do not fit in device memory.
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (128 bytes of
- *            queues per path in flight; seven waves per SIMD hide long loads).
+ *            queues per path in flight); camera rays are traced as packets.
  * MEGAKERNEL: one thread per pixel runs the whole path (the shader's own organisation).
- * PERSISTENT: one launch per batch, paths stay in registers (16 bytes per path in flight;
- *             fastest while the scene stays in cache, and for small batches). */
-enum { LPT_PIPELINE_WAVEFRONT = 0, LPT_PIPELINE_MEGAKERNEL = 1, LPT_PIPELINE_PERSISTENT = 2, LPT_PIPELINE_AUTO = 3 };
+ * PERSISTENT: one launch per batch, paths stay in registers from the camera ray on (16 bytes
+ *            per path in flight).
+ * HYBRID:    camera rays through the wavefront kernels (packets, shading at full waves), then
+ *            one persistent launch finishes the paths that go on (128 bytes per path in flight). */
+enum {
+  LPT_PIPELINE_WAVEFRONT = 0,
+  LPT_PIPELINE_MEGAKERNEL = 1,
+  LPT_PIPELINE_PERSISTENT = 2,
+  LPT_PIPELINE_AUTO = 3,
+  LPT_PIPELINE_HYBRID = 4
+};
 /* Mesh BVH builders offered by lpt_build_mesh_bvh. */
 enum { LPT_BVH_LBVH = 0 };
 

@@ -6,7 +6,7 @@ import numpy as np
 from . import _native as N
 
 BSDF_HEITZ, BSDF_BASIC = 0, 1
-PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_PERSISTENT, PIPELINE_AUTO = 0, 1, 2, 3
+PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_PERSISTENT, PIPELINE_AUTO, PIPELINE_HYBRID = 0, 1, 2, 3, 4
 BUILDER_SPLIT_BVH, BUILDER_BINNED_SAH, BUILDER_LBVH = 0, 1, 2
 
 

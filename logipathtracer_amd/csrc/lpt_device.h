@@ -110,6 +110,10 @@ struct DScene {
   uint32_t nNodes, nTris, nObjects;
 };
 
+// Queued paths carry their id in one word; bit 31 says that samples[path id] already holds the
+// radiance the path has gathered (otherwise it has gathered none yet).
+constexpr uint32_t kAccStored = 0x80000000u;
+
 // Address of record `index` as 16-byte words.  Every array here is far below 4 GiB (references
 // carry 25-bit indices), so the byte offset is formed in 32 bits: one vector instruction and the
 // addressing form "uniform base + 32-bit lane offset" instead of 64-bit multiply-adds.

@@ -53,7 +53,6 @@ struct Queue {
   float4* d;  // direction.xyz, rng.x (bits)
   float4* m;  // throughput.rgb, rng.y (bits)
 };
-constexpr uint32_t kAccStored = 0x80000000u;
 
 // Block-level append: every thread with `active` gets a distinct slot of a queue whose fill
 // count lives in *counter.  One atomic per block: a single counter word sustains only some
@@ -274,14 +273,14 @@ __global__ void k_tally(const uint32_t* __restrict__ counts, uint32_t nBounces, 
 #ifndef LPT_TRACE_WAVES_PER_SIMD
 #define LPT_TRACE_WAVES_PER_SIMD 4
 #endif
-template <int S>
+template <int S, bool QUEUED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LPT_TRACE_WAVES_PER_SIMD, LPT_TRACE_WAVES_PER_SIMD)))
 void k_trace(DScene sc, Partition P, const lpt_ubo* __restrict__ ubos,
                                                   uint32_t nFrames, uint32_t maxBounces, int bsdfMode,
                                                   float4* __restrict__ samples, uint32_t* cursor,
-                                                  unsigned long long* totals) {
+                                                  unsigned long long* totals, TraceQueue src) {
   __shared__ TraceShared<S, kBlock> sh;
-  trace_persistent<S, kBlock>(sc, P, ubos, nFrames, maxBounces, bsdfMode, samples, cursor, totals, sh);
+  trace_persistent<S, kBlock, QUEUED>(sc, P, ubos, nFrames, maxBounces, bsdfMode, samples, cursor, totals, sh, src);
 }
 
 // ---- megakernel --------------------------------------------------------------------
@@ -718,6 +717,17 @@ void launch_primary(lpt_ctx* c, const Queue& q, uint32_t count) {
                      sc.rootRef, q.o, q.d, count, c->dHits);
 }
 
+// Shading of bounce b: queue `in` with c->dHits -> queue `out`; counts at c->dCounts[b], [b+1].
+void launch_shade(lpt_ctx* c, const Queue& in, const Queue& out, uint32_t b, uint32_t nB, size_t paths) {
+  static const int resident = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, 0) != hipSuccess || n < 1) n = 4;
+    return n;
+  }();
+  hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, resident)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
+                     c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
+}
+
 int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   int rc = ensure_pool(c, frames);
   if (rc) return rc;
@@ -745,13 +755,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
       dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
     }
     LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-    static const int shadeResident = [] {
-      int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, 0) != hipSuccess || n < 1) n = 4;
-      return n;
-    }();
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, shadeResident)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
-                       c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
+    launch_shade(c, in, out, b, nB, paths);
   }
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
@@ -760,12 +764,13 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   return 0;
 }
 
-template <int S>
-void launch_trace(lpt_ctx* c, int frames) {
+// QUEUED: the paths come from `src` (at most frames * slots entries), `cursor` = kCursorRegions zeroed words.
+template <int S, bool QUEUED>
+void launch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src) {
   // persistent grid: exactly as many workgroups as are resident at once (registers and LDS decide)
   static const int resident = [] {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<S>, kBlock, 0) != hipSuccess || n < 1) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<S, QUEUED>, kBlock, 0) != hipSuccess || n < 1) n = 4;
     return n;
   }();
   int perCU = resident;
@@ -774,8 +779,18 @@ void launch_trace(lpt_ctx* c, int frames) {
   const size_t paths = (size_t)frames * c->part.nSlots;
   const size_t need = (paths + kBlock - 1) / kBlock;
   const int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
-  hipLaunchKernelGGL(k_trace<S>, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), c->part, c->dUbos,
-                     (uint32_t)frames, (uint32_t)c->maxBounces, c->bsdfMode, c->dSamples, c->dCounts, c->dTotals);
+  hipLaunchKernelGGL((k_trace<S, QUEUED>), dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), c->part, c->dUbos,
+                     (uint32_t)frames, (uint32_t)c->maxBounces, c->bsdfMode, c->dSamples, cursor, c->dTotals, src);
+}
+
+template <bool QUEUED>
+void dispatch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src) {
+  if (c->stackNeed <= 16) launch_trace<16, QUEUED>(c, frames, cursor, src);
+  else if (c->stackNeed <= 20) launch_trace<20, QUEUED>(c, frames, cursor, src);
+  else if (c->stackNeed <= 24) launch_trace<24, QUEUED>(c, frames, cursor, src);
+  else if (c->stackNeed <= 32) launch_trace<32, QUEUED>(c, frames, cursor, src);
+  else if (c->stackNeed <= 48) launch_trace<48, QUEUED>(c, frames, cursor, src);
+  else launch_trace<64, QUEUED>(c, frames, cursor, src);
 }
 
 // A batch of frames as one persistent launch plus the frame-ordered accumulation.
@@ -788,15 +803,47 @@ int render_batch_persistent(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   rc = ensure_events(c, c->evUsed + 2);
   if (rc) return rc;
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-  if (c->stackNeed <= 16) launch_trace<16>(c, frames);
-  else if (c->stackNeed <= 20) launch_trace<20>(c, frames);
-  else if (c->stackNeed <= 24) launch_trace<24>(c, frames);
-  else if (c->stackNeed <= 32) launch_trace<32>(c, frames);
-  else if (c->stackNeed <= 48) launch_trace<48>(c, frames);
-  else launch_trace<64>(c, frames);
+  dispatch_trace<false>(c, frames, c->dCounts, TraceQueue{nullptr, nullptr, nullptr, nullptr});
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
+  LPT_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// A batch of frames in two parts: the camera rays run through the wavefront kernels (generated into a
+// queue, traced as packets, their hits shaded at full waves), the paths that go on from there are
+// finished by one persistent launch that takes them from the queue.
+int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
+  int rc = ensure_pool(c, frames);
+  if (rc) return rc;
+  const size_t paths = (size_t)frames * c->part.nSlots;
+  const uint32_t nB = (uint32_t)c->maxBounces;
+  std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
+  LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorRegions) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
+  uint32_t* cursors = c->dCounts + c->poolBounces;  // poolBounces >= 2: regions of bounce 0 and bounce 1 exist
+  c->hUbos[frames].seed[0] = (uint32_t)frames * c->nValid;  // staging word behind the frame blocks
+  LPT_HIP(c, hipMemcpyAsync(c->dCounts, &c->hUbos[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  rc = ensure_events(c, c->evUsed + 2);
+  if (rc) return rc;
+  const Queue& q0 = c->queues[0];
+  const Queue& q1 = c->queues[1];
+  if (c->nValid) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
+                       (uint32_t)frames, q0, c->dValidBefore, c->nValid);
+    if (primary_packets()) launch_primary(c, q0, (uint32_t)frames * c->nValid);
+    else dispatch_extend(c, q0, c->dCounts, cursors, paths);
+    launch_shade(c, q0, q1, 0, nB, paths);
+  }
+  LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
+  if (nB > 1 && c->nValid)
+    dispatch_trace<true>(c, frames, cursors + kCursorRegions, TraceQueue{q1.o, q1.d, q1.m, c->dCounts + 1});
+  LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
+                     (uint32_t)frames, c->dSamples, c->dAccum);
+  // camera paths and their segments; the persistent launch has added the segments it traced
+  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, 1u, c->dTotals);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -1222,7 +1269,7 @@ int lpt_set_options(lpt_ctx* c, int max_bounces, int bsdf_mode, int pipeline, in
   if (max_bounces < 1 || max_bounces > 4096) return fail(c, LPT_ERR_INVALID, "max_bounces out of range");
   if (bsdf_mode != LPT_BSDF_HEITZ && bsdf_mode != LPT_BSDF_BASIC) return fail(c, LPT_ERR_INVALID, "bad bsdf_mode");
   if (pipeline != LPT_PIPELINE_WAVEFRONT && pipeline != LPT_PIPELINE_MEGAKERNEL && pipeline != LPT_PIPELINE_PERSISTENT &&
-      pipeline != LPT_PIPELINE_AUTO)
+      pipeline != LPT_PIPELINE_AUTO && pipeline != LPT_PIPELINE_HYBRID)
     return fail(c, LPT_ERR_INVALID, "bad pipeline");
   if (frames_in_flight < 0 || frames_in_flight > 4096) return fail(c, LPT_ERR_INVALID, "bad frames_in_flight");
   c->maxBounces = max_bounces;
@@ -1254,21 +1301,23 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     int fif = std::min(auto_frames_in_flight(c), n_frames);
     // path ids of a batch must leave bit 31 free (kAccStored)
     fif = std::max(1, std::min<int>(fif, (int)(0x7FFFFFFFu / std::max<uint32_t>(c->part.nSlots, 1u))));
-    // AUTO: the persistent launch, unless the scene is large and the batch too.  The persistent kernel
-    // keeps four waves per SIMD, enough while the tree and the triangles stay in an XCD's 4 MiB L2
-    // (Cornell box: 11 % ahead of the wavefront kernels at 128 Mi paths, 3.4x at 2 Mi).  On a scene
-    // that does not, the wavefront kernels' seven waves hide the longer loads better, provided a
-    // batch is large enough to amortise the tail each of their launches ends in (from about 100 Mi
-    // paths) and the ray queues fit.
+    // AUTO.  All organisations trace the camera rays as packets when they have queues.  After that:
+    //  - HYBRID (one persistent launch for everything beyond the camera rays) has no per-bounce launches
+    //    and tails: best for small and medium batches (Cornell box 1080p, one frame: 3.3x the wavefront
+    //    kernels) and, at any batch size, for scenes beyond an XCD's 4 MiB L2;
+    //  - WAVEFRONT (one extend and one shade launch per bounce) keeps seven waves per SIMD in the search
+    //    and full waves in shading: ahead once a batch is large enough to amortise its launches (from
+    //    about 100 Mi paths) on a scene that stays in cache (Cornell box: +1 % at 128 Mi paths, +6 % at 256 Mi);
+    //  - PERSISTENT (no queues, 16 instead of 128 bytes per path in flight) when the queues do not fit.
     c->activePipeline = c->pipeline;
     if (c->pipeline == LPT_PIPELINE_AUTO) {
       const double traversalBytes = 64.0 * c->nNodes + 48.0 * c->nTris;
       const bool largeScene = traversalBytes > 4.0 * 1024 * 1024;
       const bool largeBatch = (double)fif * c->part.nSlots >= 96.0 * 1024 * 1024;
-      c->activePipeline = largeScene && largeBatch ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_PERSISTENT;
+      c->activePipeline = largeBatch && !largeScene ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_HYBRID;
     }
     rc = ensure_pool(c, fif);
-    if (rc == LPT_ERR_NOMEM && c->pipeline == LPT_PIPELINE_AUTO && c->activePipeline == LPT_PIPELINE_WAVEFRONT) {
+    if (rc == LPT_ERR_NOMEM && c->pipeline == LPT_PIPELINE_AUTO) {
       c->activePipeline = LPT_PIPELINE_PERSISTENT;
       rc = ensure_pool(c, fif);
     }
@@ -1281,7 +1330,8 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
       int nb = std::min(fif, n_frames - f);
       if (f > 0) LPT_HIP(c, hipStreamSynchronize(c->stream));  // pinned ubo staging is reused
       rc = c->activePipeline == LPT_PIPELINE_PERSISTENT ? render_batch_persistent(c, ubos + f, nb)
-                                                   : render_batch_wavefront(c, ubos + f, nb);
+           : c->activePipeline == LPT_PIPELINE_HYBRID   ? render_batch_hybrid(c, ubos + f, nb)
+                                                        : render_batch_wavefront(c, ubos + f, nb);
       if (rc) return rc;
     }
   }

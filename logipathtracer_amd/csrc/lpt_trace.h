@@ -28,6 +28,9 @@ namespace lpt {
 #define LPT_NEW_MIN 12
 #endif
 // A surface round repeats the walk order while at least this many lanes are still in a walk.
+#ifndef LPT_NEW_MIN_QUEUED
+#define LPT_NEW_MIN_QUEUED 2
+#endif
 #ifndef LPT_WALK_STAY
 #define LPT_WALK_STAY 4
 #endif
@@ -44,16 +47,28 @@ struct TraceShared {
   uint32_t stack[S * BLOCK];
 };
 
-// `cursor` holds kCursorRegions zeroed words; `totals[0]` counts paths, `totals[1]` ray segments.
-template <int S, int BLOCK>
+// Where the paths of a launch come from when QUEUED: entries [0, *count) of a path queue (origin | path-id
+// word, direction | rng.x, throughput | rng.y) written by the shading of the camera rays' hits; such paths
+// start at bounce 1.
+struct TraceQueue {
+  const float4* o;
+  const float4* d;
+  const float4* m;
+  const uint32_t* count;
+};
+
+// `cursor` holds kCursorRegions zeroed words; `totals[0]` counts paths, `totals[1]` ray segments
+// (QUEUED: only the segments traced here are added).
+template <int S, int BLOCK, bool QUEUED>
 __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partition& P,
                                                  const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
                                                  uint32_t maxBounces, int bsdfMode, float4* __restrict__ samples,
                                                  uint32_t* cursor, unsigned long long* totals,
-                                                 TraceShared<S, BLOCK>& sh) {
+                                                 TraceShared<S, BLOCK>& sh, const TraceQueue& src) {
   uint32_t* stk = &sh.stack[threadIdx.x];
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t n = nFrames * P.nSlots;  // path ids of the batch: frame-major, slot-minor
+  // path ids of the batch (frame-major, slot-minor), or the queue's entries
+  const uint32_t n = QUEUED ? *src.count : nFrames * P.nSlots;
 
   // wave-uniform chunk of path ids [chunkNext, chunkEnd)
   uint32_t chunkNext = 0, chunkEnd = 0;
@@ -195,7 +210,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
       const unsigned long long bN = __ballot(state == kTsNew);
       const int nN = __popcll(bN);
       const bool othersActive = __ballot(state != kTsNew && state != kTsDone) != 0ull;
-      if (nN > 0 && (nN >= LPT_NEW_MIN || !othersActive)) {
+      // (taking a path off the queue is cheap next to generating a camera ray: no need to wait for many)
+      if (nN > 0 && (nN >= (QUEUED ? LPT_NEW_MIN_QUEUED : LPT_NEW_MIN) || !othersActive)) {
         LPT_STAT(4, nN);
         while (!exhausted && chunkNext >= chunkEnd) {
           const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
@@ -218,14 +234,33 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
             const uint32_t rank =
                 __builtin_amdgcn_mbcnt_hi((uint32_t)(bN >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bN, 0u));
             if (rank < avail) {
-              pid = chunkNext + rank;
-              const uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
-              int x, y;
-              if (slot_to_pixel(P, slot, x, y)) {
-                generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
-                bounce = 0;
+              if (QUEUED) {
+                const uint32_t i = chunkNext + rank;
+                const float4 o = src.o[i], d = src.d[i], m = src.m[i];
+                p.o = f3{o.x, o.y, o.z};
+                p.d = f3{d.x, d.y, d.z};
+                p.mask = f3{m.x, m.y, m.z};
+                p.rng = Rng{as_uint(d.w), as_uint(m.w)};
+                const uint32_t pidWord = as_uint(o.w);
+                pid = pidWord & ~kAccStored;
+                p.acc = f3{0.0f, 0.0f, 0.0f};
+                if (pidWord & kAccStored) {
+                  const float4 g = samples[pid];
+                  p.acc = f3{g.x, g.y, g.z};
+                }
+                bounce = 1;
                 ++nPaths;
                 startSearch = true;
+              } else {
+                pid = chunkNext + rank;
+                const uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
+                int x, y;
+                if (slot_to_pixel(P, slot, x, y)) {
+                  generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
+                  bounce = 0;
+                  ++nPaths;
+                  startSearch = true;
+                }
               }
             }
           }
@@ -382,7 +417,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     nPaths += (uint32_t)__shfl_down((int)nPaths, off);
   }
   if (lane == 0 && nPaths) {
-    atomicAdd(&totals[0], (unsigned long long)nPaths);
+    if (!QUEUED) atomicAdd(&totals[0], (unsigned long long)nPaths);
     atomicAdd(&totals[1], (unsigned long long)nSegments);
   }
 #ifdef LPT_TRACE_STATS

@@ -57,13 +57,14 @@ int main(int argc, char** argv) {
     else if (a == "--wavefront") pipeline = 0;
     else if (a == "--megakernel") pipeline = 1;
     else if (a == "--persistent") pipeline = 2;
+    else if (a == "--hybrid") pipeline = LPT_PIPELINE_HYBRID;
     else if (a == "--builder") builder = std::atoi(next());
     else if (a == "--out") out = next();
     else if (a[0] != '-') scenePath = a;
     else { std::cerr << "unknown option " << a << "\n"; return 2; }
   }
   if (scenePath.empty()) {
-    std::cerr << "usage: lpt_render scene.gltf [--width W --height H --spp N --bounces B --seed S --device D --basic-bsdf --wavefront | --megakernel | --persistent --builder 0|1|2 --out prefix]\n";
+    std::cerr << "usage: lpt_render scene.gltf [--width W --height H --spp N --bounces B --seed S --device D --basic-bsdf --wavefront | --megakernel | --persistent | --hybrid --builder 0|1|2 --out prefix]\n";
     return 2;
   }
   try {

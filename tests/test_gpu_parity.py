@@ -23,7 +23,7 @@ def _render_gpu(device, scene, ubos, w, h, bounces, bsdf=L.BSDF_HEITZ, pipeline=
     return img, device.stats()
 
 
-@pytest.mark.parametrize("pipeline", [L.PIPELINE_MEGAKERNEL, L.PIPELINE_WAVEFRONT, L.PIPELINE_PERSISTENT])
+@pytest.mark.parametrize("pipeline", [L.PIPELINE_MEGAKERNEL, L.PIPELINE_WAVEFRONT, L.PIPELINE_PERSISTENT, L.PIPELINE_HYBRID])
 @pytest.mark.parametrize("bounces,frames", [(2, 1), (8, 3)])
 def test_cornell_256_matches_oracle(device, cornell, cornell_oracle, pipeline, bounces, frames):
     w = h = 256
@@ -57,7 +57,7 @@ def test_full_size_config_properties(device, cornell):
     w, h, spp, bounces = 1920, 1080, 64, 8
     ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, spp)
     images, segments = [], []
-    for pipeline, fif in ((L.PIPELINE_WAVEFRONT, 0), (L.PIPELINE_PERSISTENT, 0), (L.PIPELINE_WAVEFRONT, 1),
+    for pipeline, fif in ((L.PIPELINE_WAVEFRONT, 0), (L.PIPELINE_PERSISTENT, 0), (L.PIPELINE_HYBRID, 0), (L.PIPELINE_HYBRID, 1), (L.PIPELINE_WAVEFRONT, 1),
                           (L.PIPELINE_MEGAKERNEL, 0)):
         img, st = _render_gpu(device, cornell, ubos, w, h, bounces, pipeline=pipeline, fif=fif)
         assert st.paths == w * h * spp

@@ -110,7 +110,7 @@ def test_tiny_and_degenerate_scenes_match_oracle(device, tmp_path, with_degenera
     for (w, h, bounces, frames) in ((37, 23, 3, 2), (1, 1, 1, 1), (8, 8, 16, 3)):  # ragged sizes, one pixel, deep
         ubos = L.frame_ubos(s.camera_world, s.fov_y, frames, seed=11)
         ref, st = O.render_frames(osc, ubos, w, h, bounces)
-        for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_MEGAKERNEL, L.PIPELINE_PERSISTENT):
+        for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_MEGAKERNEL, L.PIPELINE_PERSISTENT, L.PIPELINE_HYBRID):
             device.resize(w, h)
             device.set_options(bounces, L.BSDF_HEITZ, pipeline, 0)
             device.render_frames(ubos)

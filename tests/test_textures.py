@@ -167,7 +167,7 @@ def test_textured_scene_matches_oracle(device, textured, bsdf):
     osc = O.OracleScene(scene.objects, scene.object_bvh, scene.vertices, scene.mesh_bvh, scene.textures)
     ref, st = O.render_frames(osc, ubos, w, h, bounces, bsdf_mode=bsdf)
     device.upload_scene(scene)
-    for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_MEGAKERNEL, L.PIPELINE_PERSISTENT):
+    for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_MEGAKERNEL, L.PIPELINE_PERSISTENT, L.PIPELINE_HYBRID):
         device.resize(w, h)
         device.set_options(bounces, bsdf, pipeline, 0)
         device.render_frames(ubos)
