@@ -82,6 +82,19 @@ def traversal_counters(scene, ubos, width, height, bounces):
     return st
 
 
+def secondary_means(all_counters, primary_counters):
+    """Per-segment means over the segments beyond the camera rays, from the counters of a full run and of
+    a run cut after the first segment (both normalised per camera path, so the two runs may differ in size)."""
+    pa, pp = max(all_counters["paths"], 1), max(primary_counters["paths"], 1)
+    out = {}
+    seg_s = all_counters["segments"] / pa - primary_counters["segments"] / pp  # secondary segments per path
+    for k in ("boxTests", "rootVisits", "triTests", "hits"):
+        out[k] = (all_counters[k] / pa - primary_counters[k] / pp) / max(seg_s, 1e-9)
+    out["segments_per_path"] = seg_s
+    out["primary_hits_per_path"] = primary_counters["hits"] / pp
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,22 +253,37 @@ def main():
         # Roofline of the dominant kernel.  Algorithmic bytes per traced segment, in interchange terms:
         # 48 B per node fetched + 36 B per triangle tested, plus
         #   k_extend (wavefront):  24 B ray in + 12 B hit out;
-        #   k_trace (persistent):  per hit the object record and three vertices (208 + 144 B), per path
-        #                          the 16 B radiance sample (paths live in registers: no queue traffic).
+        #   k_trace:  per hit the object record and three vertices (208 + 144 B), per path the 16 B radiance
+        #             sample and, when the paths come from the queue (hybrid), the 48 B queue entry.
+        # With camera rays traced by the packet kernel the dominant kernel sees the later segments only:
+        # its means are those of the full run minus those of a run cut after the first segment.
         if counters and ext_ms > 0:
-            n_node = (counters["boxTests"] + counters["rootVisits"]) / counters["segments"]
-            n_tri = counters["triTests"] / counters["segments"]
-            p_hit = counters["hits"] / counters["segments"]
+            kernel = {0: "k_extend", 2: "k_trace", 4: "k_trace"}.get(used_pipeline, "k_megakernel")
+            packets = used_pipeline in (0, 4) and os.environ.get("LPT_PRIMARY_PACKETS", "1") != "0"
             mean_len = counters["segments"] / max(counters["paths"], 1)
-            kernel = "k_extend" if used_pipeline == 0 else ("k_trace" if used_pipeline == 2 else "k_megakernel")
+            if packets:
+                prim = traversal_counters(scene, ubos, args.width, args.height, 1)
+                sm = secondary_means(counters, prim)
+                n_node = sm["boxTests"] + sm["rootVisits"]
+                n_tri, p_hit = sm["triTests"], sm["hits"]
+                kernel_seg = float(seg) - float(paths)
+                paths_per_seg = sm["primary_hits_per_path"] / max(sm["segments_per_path"], 1e-9)
+            else:
+                n_node = (counters["boxTests"] + counters["rootVisits"]) / counters["segments"]
+                n_tri = counters["triTests"] / counters["segments"]
+                p_hit = counters["hits"] / counters["segments"]
+                kernel_seg = float(seg)
+                paths_per_seg = 1.0 / mean_len
             if kernel == "k_extend":
                 state_bytes = 24.0 + 12.0
                 state_note = "36 B ray/hit"
             else:
-                state_bytes = p_hit * (208.0 + 144.0) + 16.0 / mean_len
-                state_note = "352 B object+vertices per hit + 16 B sample per path"
+                per_path = 16.0 + (48.0 if used_pipeline == 4 else 0.0)
+                state_bytes = p_hit * (208.0 + 144.0) + per_path * paths_per_seg
+                state_note = f"352 B object+vertices per hit + {per_path:.0f} B per path"
             bytes_per_seg = 48.0 * n_node + 36.0 * n_tri + state_bytes
-            achieved = bytes_per_seg * float(seg) / (ext_ms * 1e-3) / 1e9
+            achieved = bytes_per_seg * kernel_seg / (ext_ms * 1e-3) / 1e9
+            result["kernel_segments"] = kernel_seg
             # HBM bytes per launch: PMC measurement of this workload (profiles/*_traffic.json holds bytes
             # and segments per launch of the profiled run), scaled to this run's segments per launch
             traffic = None
@@ -266,7 +294,8 @@ def main():
             if os.path.exists(tpath) and default_workload:
                 try:
                     t = json.load(open(tpath))
-                    traffic = t["hbm_bytes_per_launch"] / t["segments_per_launch"] * float(seg) / max(ext_launches, 1)
+                    if t.get("pipeline", used_pipeline) == used_pipeline:
+                        traffic = t["hbm_bytes_per_launch"] / t["segments_per_launch"] * kernel_seg / max(ext_launches, 1)
                 except Exception:
                     traffic = None
             avg_s = ext_ms * 1e-3 / max(ext_launches, 1)
@@ -274,13 +303,15 @@ def main():
                 "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "hbm_measured_gbs": (traffic / avg_s / 1e9) if traffic else None,
-                "note": f"achieved = algorithmic bytes (48 B/node fetched + 36 B/triangle + {state_note}) x segments / "
-                        f"{kernel} time; the scene is cache-resident, so measured HBM traffic is far lower and the "
-                        "kernel is bound by the L1 gather path and vector issue, not by HBM",
+                "note": f"achieved = algorithmic bytes (48 B/node fetched + 36 B/triangle + {state_note}) x the segments "
+                        f"{kernel} traced" + (" (all but the camera rays, which the packet kernel k_primary traces)"
+                                              if packets else "")
+                        + f" / {kernel} time; the scene is cache-resident, so measured HBM traffic is far lower and "
+                        "the kernel is bound by the L1 gather path and vector issue, not by HBM",
                 "bytes_per_segment": bytes_per_seg, "nodes_per_segment": n_node, "tris_per_segment": n_tri,
                 "hits_per_segment": p_hit,
                 "avg_launch_ms": ext_ms / max(ext_launches, 1), "launches": ext_launches,
-                "segments_per_launch": float(seg) / max(ext_launches, 1),
+                "segments_per_launch": kernel_seg / max(ext_launches, 1),
             }
         else:
             result["roofline"] = None

@@ -117,7 +117,8 @@ typedef struct lpt_stats {
   uint64_t segments;      /* ray segments traced (iterations of traceRay's loop) */
   uint64_t frames;        /* frames rendered */
   double   device_ms;     /* HIP-event time of the whole call on the context's stream */
-  double   extend_ms;     /* summed HIP-event time of the traversal kernel launches */
+  double   extend_ms;     /* summed HIP-event time of the launches of the dominant kernel: k_extend
+                             (wavefront; the camera rays' packet kernel is not among them) or k_trace */
   uint32_t extend_launches;
   uint32_t pipeline;      /* organisation the call ran with (what LPT_PIPELINE_AUTO resolved to) */
 } lpt_stats;

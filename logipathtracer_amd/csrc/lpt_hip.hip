@@ -748,13 +748,13 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   for (uint32_t b = 0; b < nB; ++b) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
-    LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     if (b == 0 && primary_packets()) {
       launch_primary(c, in, (uint32_t)frames * c->nValid);
-    } else {
+    } else {  // the k_extend launches are timed one by one (lpt_stats.extend_ms)
+      LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
       dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
+      LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     }
-    LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     launch_shade(c, in, out, b, nB, paths);
   }
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,

@@ -56,19 +56,21 @@ for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_tr
     write, nw = per_dispatch("WRITE_SIZE", kernel)
     if fetch is None or write is None:
         continue
-    segs = None
+    segs, pipe = None, None
     try:
         b = json.load(open(os.path.join(src, "fetch.json")))
-        segs = b["traced_segments"] / b["extend_launches_rank0"]
+        segs = b.get("kernel_segments", b["traced_segments"]) / b["extend_launches_rank0"]
+        pipe = {"wavefront": 0, "persistent": 2, "hybrid": 4}.get(b["config"]["pipeline"].split()[0])
     except Exception:
         pass
     traffic = {
         "kernel": kernel,
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
-                   + (" --pipeline 0" if kernel == "k_extend" else ""),
+                   + (f" --pipeline {pipe}" if pipe is not None else ""),
         "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write, "launches": nf,
         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
         "segments_per_launch": segs,
+        "pipeline": pipe,
         "rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B reads as 64 B)",
     }
     json.dump(traffic, open(os.path.join(dst, fname), "w"), indent=1)
