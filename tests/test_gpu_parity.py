@@ -51,7 +51,7 @@ def test_basic_bsdf_matches_oracle(device, cornell, cornell_oracle):
 @pytest.mark.gpu
 def test_full_size_config_properties(device, cornell):
     """The benchmark's configuration at full size (1920x1080, 64 spp, 8 bounces), where the oracle is too
-    slow to compare against: properties that do not depend on size.  The three kernel organisations
+    slow to compare against: properties that do not depend on size.  The four kernel organisations
     produce the same bits; alpha counts the samples; one batch of 64 frames equals 64 batches of one;
     paths = W*H*spp and every path traces between 1 and 8 segments."""
     w, h, spp, bounces = 1920, 1080, 64, 8
