@@ -113,13 +113,14 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __re
   extend_persistent<S, kBlock>(sc, qo, qd, *count, hits, cursor, stack);
 }
 
-// Closest hit for the queued camera rays, 64 consecutive rays (one pixel block) per wave walked as a
-// packet with wave-uniform record loads.  See lpt_primary.h.
+// Camera rays of a batch: generated, queued for the shading kernel and traced, 64 consecutive path ids
+// (one pixel block) per wave walked as a packet with wave-uniform record loads.  See lpt_primary.h.
 __global__ __launch_bounds__(kBlock) void k_primary(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
-                                                    const ObjTrav* __restrict__ otrav, uint32_t rootRef,
-                                                    const float4* __restrict__ qo, const float4* __restrict__ qd,
-                                                    uint32_t count, float4* __restrict__ hits) {
-  primary_packet(nodes, tris, otrav, rootRef, qo, qd, count, hits);
+                                                    const ObjTrav* __restrict__ otrav, uint32_t rootRef, Partition P,
+                                                    const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
+                                                    const uint32_t* __restrict__ validBefore, uint32_t nValid,
+                                                    PrimaryQueue q, float4* __restrict__ hits) {
+  primary_packet(nodes, tris, otrav, rootRef, P, ubos, nFrames, validBefore, nValid, q, hits);
 }
 
 // Shades queue entry i (a ray that hit something), samples the next direction, applies Russian
@@ -709,12 +710,14 @@ bool primary_packets() {
   return on;
 }
 
-// Closest hits of the `count` camera rays at the head of queue `q` (in path-id order) into c->dHits.
-void launch_primary(lpt_ctx* c, const Queue& q, uint32_t count) {
-  if (count == 0) return;
+// Camera rays of `frames` frames into queue `q` (as k_generate leaves them) and their closest hits into c->dHits.
+void launch_primary(lpt_ctx* c, const Queue& q, int frames) {
+  const size_t paths = (size_t)frames * c->part.nSlots;
+  if (paths == 0 || c->nValid == 0) return;
   const DScene sc = device_scene(c);
-  hipLaunchKernelGGL(k_primary, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, sc.nodes, sc.tris, sc.otrav,
-                     sc.rootRef, q.o, q.d, count, c->dHits);
+  hipLaunchKernelGGL(k_primary, dim3((unsigned)((paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sc.nodes, sc.tris,
+                     sc.otrav, sc.rootRef, c->part, c->dUbos, (uint32_t)frames, c->dValidBefore, c->nValid,
+                     PrimaryQueue{q.o, q.d, q.m}, c->dHits);
 }
 
 // Shading of bounce b: queue `in` with c->dHits -> queue `out`; counts at c->dCounts[b], [b+1].
@@ -740,7 +743,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   // the first queue is filled in path-id order, its count is known here
   c->hUbos[frames].seed[0] = (uint32_t)frames * c->nValid;  // staging word behind the frame blocks
   LPT_HIP(c, hipMemcpyAsync(c->dCounts, &c->hUbos[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  if (c->nValid)
+  if (c->nValid && !primary_packets())  // the packet kernel generates the camera rays itself
     hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                        (uint32_t)frames, c->queues[0], c->dValidBefore, c->nValid);
   rc = ensure_events(c, c->evUsed + 2 * (size_t)nB);
@@ -749,7 +752,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
     if (b == 0 && primary_packets()) {
-      launch_primary(c, in, (uint32_t)frames * c->nValid);
+      launch_primary(c, in, frames);
     } else {  // the k_extend launches are timed one by one (lpt_stats.extend_ms)
       LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
       dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
@@ -830,10 +833,13 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   const Queue& q0 = c->queues[0];
   const Queue& q1 = c->queues[1];
   if (c->nValid) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
-                       (uint32_t)frames, q0, c->dValidBefore, c->nValid);
-    if (primary_packets()) launch_primary(c, q0, (uint32_t)frames * c->nValid);
-    else dispatch_extend(c, q0, c->dCounts, cursors, paths);
+    if (primary_packets()) {
+      launch_primary(c, q0, frames);
+    } else {
+      hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
+                         (uint32_t)frames, q0, c->dValidBefore, c->nValid);
+      dispatch_extend(c, q0, c->dCounts, cursors, paths);
+    }
     launch_shade(c, q0, q1, 0, nB, paths);
   }
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));

@@ -42,22 +42,40 @@ __device__ __forceinline__ void packet_pop(const PacketStack& st, int& sp, uint3
   mask = ((unsigned long long)hi << 32) | lo;
 }
 
-// Rays i in [0, nRays) come from the queue arrays qo / qd (xyz); hits[i] = (t, obj, prim, 0).  The camera
-// rays are queued in path-id order (frame-major, slot-minor) and 64 consecutive slots are one 8x8 pixel
-// block, so the wave of threads [64w, 64w+64) holds one block of one frame.
+// What the packet kernel does with the camera rays it generates, besides tracing them: queue them for the
+// shading kernel (origin | path id, direction | rng.x, throughput | rng.y, as k_generate does).
+struct PrimaryQueue {
+  float4* o;
+  float4* d;
+  float4* m;
+};
+
+// Thread t of the launch owns path id t (frame-major, slot-minor; 64 consecutive slots are one 8x8 pixel
+// block, so a wave holds one block of one frame).  Its camera ray is generated here, queued at index
+// f*nValid + validBefore[slot] (or the path id itself when validBefore is null: every slot a pixel) and
+// traced; hits[same index] = (t, obj, prim, 0).
 __device__ __forceinline__ void primary_packet(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
                                                const ObjTrav* __restrict__ otrav, uint32_t rootRef,
-                                               const float4* __restrict__ qo, const float4* __restrict__ qd,
-                                               uint32_t nRays, float4* __restrict__ hits) {
+                                               const Partition& P, const lpt_ubo* __restrict__ ubos,
+                                               uint32_t nFrames, const uint32_t* __restrict__ validBefore,
+                                               uint32_t nValid, const PrimaryQueue& q, float4* __restrict__ hits) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < nRays;
+  const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = pid < nFrames * P.nSlots;
+  uint32_t i = pid;
   Path p;
   p.o = p.d = f3{0.0f, 0.0f, 1.0f};
   if (valid) {
-    const float4 o = qo[i], d = qd[i];
-    p.o = f3{o.x, o.y, o.z};
-    p.d = f3{d.x, d.y, d.z};
+    const uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
+    int x, y;
+    valid = slot_to_pixel(P, slot, x, y);
+    if (valid) {
+      generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
+      if (validBefore) i = f * nValid + validBefore[slot];
+      q.o[i] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pid));
+      q.d[i] = make_float4(p.d.x, p.d.y, p.d.z, as_float(p.rng.x));
+      q.m[i] = make_float4(p.mask.x, p.mask.y, p.mask.z, as_float(p.rng.y));
+    }
   }
   unsigned long long mask = __ballot(valid);
   if (mask == 0ull) return;  // the whole wave at once
