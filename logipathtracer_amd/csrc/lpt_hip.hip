@@ -120,7 +120,11 @@ __global__ __launch_bounds__(kBlock) void k_primary(const TNode* __restrict__ no
                                                     const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
                                                     const uint32_t* __restrict__ validBefore, uint32_t nValid,
                                                     PrimaryQueue q, float4* __restrict__ hits) {
-  primary_packet(nodes, tris, otrav, rootRef, P, ubos, nFrames, validBefore, nValid, q, hits);
+  Path p;
+  Hit hit;
+  bool valid;
+  uint32_t pid;
+  primary_packet<true>(nodes, tris, otrav, rootRef, P, ubos, nFrames, validBefore, nValid, q, hits, p, hit, valid, pid);
 }
 
 // Shades queue entry i (a ray that hit something), samples the next direction, applies Russian
@@ -235,6 +239,40 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
   }
   for (int c = 0; c < kShadeClasses; ++c)
     if (nPending[c] > 0) shade_list(c, nPending[c]);
+}
+
+// The first segment of every path of a batch in one kernel: camera ray, packet walk (as k_primary) and
+// the shading of what it hit (as k_shade does for bounce 0, without the detour through a ray queue and a
+// hit array).  The pixels of a block mostly hit the same object, so the lanes shade in step without the
+// sorting k_shade does.  Paths that go on are appended to `out`.
+__global__ __launch_bounds__(kBlock) void k_primary_shade(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
+                                                          const ObjTrav* __restrict__ otrav, DScene sc, Partition P,
+                                                          const lpt_ubo* __restrict__ ubos, uint32_t nFrames, Queue out,
+                                                          uint32_t* countOut, float4* __restrict__ samples,
+                                                          uint32_t maxBounces, int bsdfMode) {
+  __shared__ uint32_t lds[kBlock / 64 + 1];
+  Path p;
+  Hit hit;
+  bool valid;
+  uint32_t pid;
+  primary_packet<false>(nodes, tris, otrav, sc.rootRef, P, ubos, nFrames, nullptr, 0u, PrimaryQueue{nullptr, nullptr, nullptr},
+                        nullptr, p, hit, valid, pid);
+  bool alive = false;
+  uint32_t pidWord = pid;
+  if (valid) {
+    f3 s{0.0f, 0.0f, 0.0f};
+    alive = shade_hit<true>(sc, p, hit, 0u, maxBounces, bsdfMode, s);  // a miss ends the path with s = 0.2 * throughput
+    if (hit.t == kInfinity) {
+      samples[pid] = make_float4(s.x, s.y, s.z, 0.0f);
+    } else if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
+      samples[pid] = make_float4(p.acc.x, p.acc.y, p.acc.z, 0.0f);  // emitted by the first hit
+      pidWord |= kAccStored;
+    } else if (!alive) {
+      samples[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  }
+  const uint32_t dst = block_append(alive, countOut, lds);
+  if (alive) store_path(out, dst, p, pidWord);
 }
 
 // Adds the finished frames to the accumulation image in frame order
@@ -720,6 +758,22 @@ void launch_primary(lpt_ctx* c, const Queue& q, int frames) {
                      PrimaryQueue{q.o, q.d, q.m}, c->dHits);
 }
 
+// Unless LPT_PRIMARY_FUSED=0 (comparison runs), the packet kernel also shades what the camera rays hit.
+bool primary_fused() {
+  static const bool on = !(std::getenv("LPT_PRIMARY_FUSED") && std::atoi(std::getenv("LPT_PRIMARY_FUSED")) == 0);
+  return on;
+}
+
+// The whole first segment of `frames` frames: paths that go on land in queue `out`, count at c->dCounts[1].
+void launch_primary_shade(lpt_ctx* c, const Queue& out, int frames) {
+  const size_t paths = (size_t)frames * c->part.nSlots;
+  if (paths == 0 || c->nValid == 0) return;
+  const DScene sc = device_scene(c);
+  hipLaunchKernelGGL(k_primary_shade, dim3((unsigned)((paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sc.nodes,
+                     sc.tris, sc.otrav, sc, c->part, c->dUbos, (uint32_t)frames, out, c->dCounts + 1, c->dSamples,
+                     (uint32_t)c->maxBounces, c->bsdfMode);
+}
+
 // Shading of bounce b: queue `in` with c->dHits -> queue `out`; counts at c->dCounts[b], [b+1].
 void launch_shade(lpt_ctx* c, const Queue& in, const Queue& out, uint32_t b, uint32_t nB, size_t paths) {
   static const int resident = [] {
@@ -751,6 +805,10 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   for (uint32_t b = 0; b < nB; ++b) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
+    if (b == 0 && primary_packets() && primary_fused()) {
+      launch_primary_shade(c, out, frames);
+      continue;
+    }
     if (b == 0 && primary_packets()) {
       launch_primary(c, in, frames);
     } else {  // the k_extend launches are timed one by one (lpt_stats.extend_ms)
@@ -833,14 +891,17 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   const Queue& q0 = c->queues[0];
   const Queue& q1 = c->queues[1];
   if (c->nValid) {
-    if (primary_packets()) {
+    if (primary_packets() && primary_fused()) {
+      launch_primary_shade(c, q1, frames);
+    } else if (primary_packets()) {
       launch_primary(c, q0, frames);
+      launch_shade(c, q0, q1, 0, nB, paths);
     } else {
       hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                          (uint32_t)frames, q0, c->dValidBefore, c->nValid);
       dispatch_extend(c, q0, c->dCounts, cursors, paths);
+      launch_shade(c, q0, q1, 0, nB, paths);
     }
-    launch_shade(c, q0, q1, 0, nB, paths);
   }
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   if (nB > 1 && c->nValid)

@@ -51,44 +51,50 @@ struct PrimaryQueue {
 };
 
 // Thread t of the launch owns path id t (frame-major, slot-minor; 64 consecutive slots are one 8x8 pixel
-// block, so a wave holds one block of one frame).  Its camera ray is generated here, queued at index
-// f*nValid + validBefore[slot] (or the path id itself when validBefore is null: every slot a pixel) and
-// traced; hits[same index] = (t, obj, prim, 0).
+// block, so a wave holds one block of one frame).  Its camera ray is generated here and traced; on return
+// `valid` says whether the path id is a pixel of the image, `p` is the path at its first segment and `hit`
+// what that segment found.  With STORE the ray is also queued at index f*nValid + validBefore[slot] (or the
+// path id itself when validBefore is null: every slot a pixel) and hits[same index] = (t, obj, prim, 0).
+// Every thread returns (no early exit), so the caller may synchronise the workgroup afterwards.
+template <bool STORE>
 __device__ __forceinline__ void primary_packet(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
                                                const ObjTrav* __restrict__ otrav, uint32_t rootRef,
                                                const Partition& P, const lpt_ubo* __restrict__ ubos,
                                                uint32_t nFrames, const uint32_t* __restrict__ validBefore,
-                                               uint32_t nValid, const PrimaryQueue& q, float4* __restrict__ hits) {
+                                               uint32_t nValid, const PrimaryQueue& q, float4* __restrict__ hits,
+                                               Path& p, Hit& hit, bool& valid, uint32_t& pid) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
-  bool valid = pid < nFrames * P.nSlots;
+  pid = blockIdx.x * blockDim.x + threadIdx.x;
+  valid = pid < nFrames * P.nSlots;
   uint32_t i = pid;
-  Path p;
   p.o = p.d = f3{0.0f, 0.0f, 1.0f};
+  p.mask = p.acc = f3{0.0f, 0.0f, 0.0f};
+  p.rng = Rng{0u, 0u};
   if (valid) {
     const uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
     int x, y;
     valid = slot_to_pixel(P, slot, x, y);
     if (valid) {
       generate_ray(ubos[f], x, y, (float)P.W, (float)P.H, p);
-      if (validBefore) i = f * nValid + validBefore[slot];
-      q.o[i] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pid));
-      q.d[i] = make_float4(p.d.x, p.d.y, p.d.z, as_float(p.rng.x));
-      q.m[i] = make_float4(p.mask.x, p.mask.y, p.mask.z, as_float(p.rng.y));
+      if (STORE) {
+        if (validBefore) i = f * nValid + validBefore[slot];
+        q.o[i] = make_float4(p.o.x, p.o.y, p.o.z, as_float(pid));
+        q.d[i] = make_float4(p.d.x, p.d.y, p.d.z, as_float(p.rng.x));
+        q.m[i] = make_float4(p.mask.x, p.mask.y, p.mask.z, as_float(p.rng.y));
+      }
     }
   }
   unsigned long long mask = __ballot(valid);
-  if (mask == 0ull) return;  // the whole wave at once
 
   const f3 wo = p.o, wd = p.d;
   const f3 winv{1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z};
   f3 co = wo, cd = wd, cinv = winv;
-  Hit hit{kInfinity, 0u, 0u};
+  hit = Hit{kInfinity, 0u, 0u};
 
   PacketStack st{0u, 0u, 0u};
   int sp = 0;
   packet_push(st, sp, lane, kRefSentinel, 0ull);
-  uint32_t cur = rootRef;
+  uint32_t cur = mask != 0ull ? rootRef : kRefSentinel;  // a wave without pixels has nothing to walk
   uint32_t curObj = 0u;
   bool inObj = false;
 
@@ -156,7 +162,7 @@ __device__ __forceinline__ void primary_packet(const TNode* __restrict__ nodes, 
       inObj = true;
     }
   }
-  if (valid) hits[i] = make_float4(hit.t, as_float(hit.obj), as_float(hit.prim), 0.0f);
+  if (STORE && valid) hits[i] = make_float4(hit.t, as_float(hit.obj), as_float(hit.prim), 0.0f);
 }
 
 }  // namespace lpt
