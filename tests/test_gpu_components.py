@@ -155,7 +155,7 @@ def test_tile_sharding_reproduces_the_whole_image(cornell, cornell_oracle):
         dev.upload_scene(cornell)
         dev.resize(w, h)
         dev.set_partition(tile, tile, r, ranks)
-        dev.set_options(bounces, L.BSDF_HEITZ, L.PIPELINE_WAVEFRONT, 0)
+        dev.set_options(bounces, L.BSDF_HEITZ, (L.PIPELINE_WAVEFRONT, L.PIPELINE_HYBRID, L.PIPELINE_PERSISTENT)[r % 3], 0)
         dev.render_frames(ubos)
         seg += dev.stats().segments
         assert dev.owned_slots() == P.n_slots

@@ -24,7 +24,7 @@ def _render_gpu(device, scene, ubos, w, h, bounces, bsdf=L.BSDF_HEITZ, pipeline=
 
 
 @pytest.mark.parametrize("pipeline", [L.PIPELINE_MEGAKERNEL, L.PIPELINE_WAVEFRONT, L.PIPELINE_PERSISTENT, L.PIPELINE_HYBRID])
-@pytest.mark.parametrize("bounces,frames", [(2, 1), (8, 3)])
+@pytest.mark.parametrize("bounces,frames", [(1, 2), (2, 1), (8, 3)])
 def test_cornell_256_matches_oracle(device, cornell, cornell_oracle, pipeline, bounces, frames):
     w = h = 256
     ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, frames)
@@ -37,6 +37,29 @@ def test_cornell_256_matches_oracle(device, cornell, cornell_oracle, pipeline, b
     mism = int((img[..., :3] != ref[..., :3]).any(axis=-1).sum())
     print(f"rel_l2={err:.3e} mismatching_pixels={mism}")
     assert err <= TOL
+
+
+def test_odd_image_size_and_sharded_first_segment(device, cornell, cornell_oracle):
+    """An image whose sides are no multiples of the 8x8 pixel blocks, rendered whole and as rank 1 of 3:
+    the packet kernel's waves then hold slots that are no pixels."""
+    w, h, bounces = 203, 77, 5
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, 2, seed=11)
+    ref, st = O.render_frames(cornell_oracle, ubos, w, h, bounces)
+    for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_HYBRID, L.PIPELINE_PERSISTENT):
+        img, gst = _render_gpu(device, cornell, ubos, w, h, bounces, pipeline=pipeline)
+        assert gst.segments == st["segments"]
+        assert np.array_equal(img, ref)
+        dev = L.Device(0)
+        dev.upload_scene(cornell)
+        dev.resize(w, h)
+        dev.set_partition(16, 16, 1, 3)
+        dev.set_options(bounces, L.BSDF_HEITZ, pipeline, 0)
+        dev.render_frames(ubos)
+        part = dev.read_accum()
+        dev.close()
+        owned = part[..., 3] > 0
+        assert owned.any() and not owned.all()
+        assert np.array_equal(part[owned], ref[owned])
 
 
 def test_basic_bsdf_matches_oracle(device, cornell, cornell_oracle):
