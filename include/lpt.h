@@ -98,7 +98,7 @@ enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
  * PERSISTENT: one launch per batch, paths stay in registers from the camera ray on (16 bytes
  *            per path in flight).
  * HYBRID:    camera rays through the wavefront kernels (packets, shading at full waves), then
- *            one persistent launch finishes the paths that go on (128 bytes per path in flight). */
+ *            one persistent launch finishes the paths that go on (64 bytes per path in flight). */
 enum {
   LPT_PIPELINE_WAVEFRONT = 0,
   LPT_PIPELINE_MEGAKERNEL = 1,

@@ -659,17 +659,32 @@ int auto_frames_in_flight(const lpt_ctx* c) {
   if (c->framesInFlight > 0) return c->framesInFlight;
   // Every traversal launch ends with a latency-bound tail (its longest rays, about half a
   // millisecond whatever the number of rays), so large batches pay off: aim for 256 Mi paths in
-  // flight (about 34 GB of queues at 128 B per path; 1080p: 128 frames).  Measured on MI355X,
-  // Cornell box 1080p: 32 frames in flight 4.9, 64: 5.4, 128: 5.7 Gsamples/s.
+  // flight (about 34 GB of queues at 128 B per path, 17 GB for the hybrid organisation's 64 B;
+  // 1080p: 128 frames).  Measured on MI355X, Cornell box 1080p, wavefront kernels: 32 frames in
+  // flight 7.0, 64: 7.9, 128: 8.4 Gsamples/s.
   const double target = 256.0 * 1024 * 1024;
   int f = (int)(target / std::max<uint32_t>(c->part.nSlots, 1u));
   return std::min(2048, std::max(1, f));
 }
 
+// Camera rays are traced as packets unless LPT_PRIMARY_PACKETS=0 (comparison runs).
+bool primary_packets() {
+  static const bool on = !(std::getenv("LPT_PRIMARY_PACKETS") && std::atoi(std::getenv("LPT_PRIMARY_PACKETS")) == 0);
+  return on;
+}
+
+// Unless LPT_PRIMARY_FUSED=0 (comparison runs), the packet kernel also shades what the camera rays hit.
+bool primary_fused() {
+  static const bool on = !(std::getenv("LPT_PRIMARY_FUSED") && std::atoi(std::getenv("LPT_PRIMARY_FUSED")) == 0);
+  return on;
+}
+
 int ensure_pool(lpt_ctx* c, int frames) {
   size_t paths = (size_t)frames * c->part.nSlots;
-  // wavefront: 2 queues x 3 arrays + hits + samples = 8 float4 arrays; persistent: samples only
-  const int arrays = c->activePipeline == LPT_PIPELINE_PERSISTENT ? 1 : 8;
+  // float4 arrays of one entry per path: wavefront 2 queues x 3 + hits + samples = 8; hybrid with the fused
+  // first segment the queue it writes + samples = 4; persistent samples only
+  const bool oneQueue = c->activePipeline == LPT_PIPELINE_HYBRID && primary_packets() && primary_fused();
+  const int arrays = c->activePipeline == LPT_PIPELINE_PERSISTENT ? 1 : (oneQueue ? 4 : 8);
   if (paths > c->poolPaths || arrays != c->poolArrays) {
     dfree(c->dPool);
     c->poolPaths = 0;
@@ -679,12 +694,14 @@ int ensure_pool(lpt_ctx* c, int frames) {
       return fail(c, LPT_ERR_NOMEM, "not enough device memory for " + std::to_string(frames) + " frames in flight");
     }
     float4* p = c->dPool;
+    c->queues[0] = c->queues[1] = Queue{nullptr, nullptr, nullptr};
+    c->dHits = nullptr;
+    for (int q = arrays == 8 ? 0 : 1; q < 2 && arrays > 1; ++q) {
+      c->queues[q].o = p; p += paths;
+      c->queues[q].d = p; p += paths;
+      c->queues[q].m = p; p += paths;
+    }
     if (arrays == 8) {
-      for (int q = 0; q < 2; ++q) {
-        c->queues[q].o = p; p += paths;
-        c->queues[q].d = p; p += paths;
-        c->queues[q].m = p; p += paths;
-      }
       c->dHits = p; p += paths;
     }
     c->dSamples = p;
@@ -742,12 +759,6 @@ int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t*
   return launch_extend<64>(c, q, count, cursor, maxItems);
 }
 
-// Camera rays are traced as packets unless LPT_PRIMARY_PACKETS=0 (comparison runs).
-bool primary_packets() {
-  static const bool on = !(std::getenv("LPT_PRIMARY_PACKETS") && std::atoi(std::getenv("LPT_PRIMARY_PACKETS")) == 0);
-  return on;
-}
-
 // Camera rays of `frames` frames into queue `q` (as k_generate leaves them) and their closest hits into c->dHits.
 void launch_primary(lpt_ctx* c, const Queue& q, int frames) {
   const size_t paths = (size_t)frames * c->part.nSlots;
@@ -756,12 +767,6 @@ void launch_primary(lpt_ctx* c, const Queue& q, int frames) {
   hipLaunchKernelGGL(k_primary, dim3((unsigned)((paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sc.nodes, sc.tris,
                      sc.otrav, sc.rootRef, c->part, c->dUbos, (uint32_t)frames, c->dValidBefore, c->nValid,
                      PrimaryQueue{q.o, q.d, q.m}, c->dHits);
-}
-
-// Unless LPT_PRIMARY_FUSED=0 (comparison runs), the packet kernel also shades what the camera rays hit.
-bool primary_fused() {
-  static const bool on = !(std::getenv("LPT_PRIMARY_FUSED") && std::atoi(std::getenv("LPT_PRIMARY_FUSED")) == 0);
-  return on;
 }
 
 // The whole first segment of `frames` frames: paths that go on land in queue `out`, count at c->dCounts[1].
