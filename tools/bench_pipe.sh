@@ -1,5 +1,5 @@
 #!/bin/bash
-# Short bench of one pipeline (0 wavefront, 1 megakernel, 2 persistent); prints the numbers that matter.
+# Short bench of one pipeline (0 wavefront, 1 megakernel, 2 persistent, 3 automatic, 4 hybrid); prints the numbers that matter.
 P=${1:-2}; shift
 timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --pipeline $P "$@" 2>/dev/null | python3 -c "
 import json,sys
