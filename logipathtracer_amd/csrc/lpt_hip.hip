@@ -491,7 +491,6 @@ struct lpt_ctx {
   int pipeline = LPT_PIPELINE_AUTO;
   int activePipeline = LPT_PIPELINE_WAVEFRONT;  // what AUTO resolved to for the current call
   int framesInFlight = 0;
-  int extendBlocksPerCU = 8;
 
   // wavefront pool
   size_t poolPaths = 0;
