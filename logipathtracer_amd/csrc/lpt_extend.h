@@ -20,9 +20,9 @@
 // The scene is read from global memory.  Each step gathers one 64-byte node, 48-byte triangle or
 // 64-byte object record per lane at unrelated addresses; the L1 serves such loads lane by lane and
 // that, together with vector issue, is what bounds the kernel (not HBM: the hot part of the scene
-// sits in L1/L2).  LDS copies of the hottest nodes, triangles and object records (tried from 16
-// nodes per workgroup to 768 nodes + 512 triangles) were no faster: random 16-byte reads cost the
-// LDS what they cost the L1.
+// sits in L1/L2).  A few of the hottest nodes are kept in LDS (a second, parallel path for 16-byte
+// gathers); larger LDS copies of nodes, triangles and object records cost resident workgroups and
+// were slower: random 16-byte reads cost the LDS what they cost the L1.
 #pragma once
 #include "lpt_device.h"
 
@@ -60,12 +60,24 @@ constexpr uint32_t kCursorRegions = 8;
 constexpr int kBurstTriFree = 4;
 constexpr int kStFetch = 0, kStInner = 1, kStTri = 2, kStObj = 3, kStDone = 4;
 
-// `stack` is the workgroup's LDS array of S entries per thread, laid out [entry][thread].
-template <int S, int BLOCK>
+// The first CACHE derived nodes (the array is ordered hottest first) are kept in LDS with a stride of
+// kCacheStride words: 80 bytes, so that 16-byte reads at unrelated nodes spread over all banks.
+constexpr int kCacheStride = 20;
+
+// `stack` is the workgroup's LDS array of S entries per thread, laid out [entry][thread]; `cache` one of
+// CACHE * kCacheStride words (unused if CACHE == 0).
+template <int S, int BLOCK, int CACHE>
 __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4* __restrict__ qo,
                                                   const float4* __restrict__ qd, uint32_t n,
-                                                  float4* __restrict__ hits, uint32_t* cursor, uint32_t* stack) {
+                                                  float4* __restrict__ hits, uint32_t* cursor, uint32_t* stack,
+                                                  float* cache) {
   uint32_t* stk = &stack[threadIdx.x];
+  if (CACHE > 0) {
+    const uint32_t words = min((uint32_t)CACHE, sc.nNodes) * 16u;
+    const float* src = reinterpret_cast<const float*>(sc.nodes);
+    for (uint32_t w = threadIdx.x; w < words; w += BLOCK) cache[(w >> 4) * kCacheStride + (w & 15u)] = src[w];
+    __syncthreads();
+  }
   const uint32_t lane = threadIdx.x & 63u;
 
   // wave-uniform chunk of ray indices [chunkNext, chunkEnd)
@@ -145,8 +157,20 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       LPT_XSTAT(1, nI);
       if (state == kStInner) {
         for (;;) {
-          const float4* q = record_words(sc.nodes, cur);
-          const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+          float4 q0, q1, q2, q3;
+          if (CACHE > 0 && cur < (uint32_t)CACHE) {
+            const float4* q = reinterpret_cast<const float4*>(cache + cur * kCacheStride);
+            q0 = q[0];
+            q1 = q[1];
+            q2 = q[2];
+            q3 = q[3];
+          } else {
+            const float4* q = record_words(sc.nodes, cur);
+            q0 = q[0];
+            q1 = q[1];
+            q2 = q[2];
+            q3 = q[3];
+          }
           bool h0, h1;
           box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
           const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
