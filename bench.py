@@ -82,16 +82,16 @@ def traversal_counters(scene, ubos, width, height, bounces):
     return st
 
 
-def secondary_means(all_counters, primary_counters):
-    """Per-segment means over the segments beyond the camera rays, from the counters of a full run and of
-    a run cut after the first segment (both normalised per camera path, so the two runs may differ in size)."""
-    pa, pp = max(all_counters["paths"], 1), max(primary_counters["paths"], 1)
-    out = {}
-    seg_s = all_counters["segments"] / pa - primary_counters["segments"] / pp  # secondary segments per path
-    for k in ("boxTests", "rootVisits", "triTests", "hits"):
-        out[k] = (all_counters[k] / pa - primary_counters[k] / pp) / max(seg_s, 1e-9)
-    out["segments_per_path"] = seg_s
-    out["primary_hits_per_path"] = primary_counters["hits"] / pp
+def range_means(upto_hi, upto_lo):
+    """Per-segment means over the segments of bounces [lo, hi), from the counters of oracle runs cut after
+    hi and after lo segments (both normalised per camera path, so the runs may differ in size; upto_lo is
+    None for lo = 0)."""
+    ph = max(upto_hi["paths"], 1)
+    pl = max(upto_lo["paths"], 1) if upto_lo else 1
+    lo = (lambda k: upto_lo[k] / pl) if upto_lo else (lambda k: 0.0)
+    seg = upto_hi["segments"] / ph - lo("segments")  # segments of the range per camera path
+    out = {k: (upto_hi[k] / ph - lo(k)) / max(seg, 1e-9) for k in ("boxTests", "rootVisits", "triTests", "hits")}
+    out["segments_per_path"] = seg
     return out
 
 
@@ -154,7 +154,7 @@ def main():
         run_step(i)
     barrier()
     t0 = time.perf_counter()
-    seg = paths = 0
+    seg = paths = kernel_seg_total = 0
     ext_ms = 0.0
     ext_launches = 0
     dev_ms = 0.0
@@ -162,6 +162,7 @@ def main():
         run_step(i)
         st = dev.stats()  # waits for the step; counters and HIP-event times of this step
         seg += st.segments
+        kernel_seg_total += st.kernel_segments
         paths += st.paths
         ext_ms += st.extend_ms
         ext_launches += st.extend_launches
@@ -260,20 +261,23 @@ def main():
         if counters and ext_ms > 0:
             kernel = {0: "k_extend", 2: "k_trace", 4: "k_trace"}.get(used_pipeline, "k_megakernel")
             packets = used_pipeline in (0, 4) and os.environ.get("LPT_PRIMARY_PACKETS", "1") != "0"
-            mean_len = counters["segments"] / max(counters["paths"], 1)
-            if packets:
-                prim = traversal_counters(scene, ubos, args.width, args.height, 1)
-                sm = secondary_means(counters, prim)
-                n_node = sm["boxTests"] + sm["rootVisits"]
-                n_tri, p_hit = sm["triTests"], sm["hits"]
-                kernel_seg = float(seg) - float(paths)
-                paths_per_seg = sm["primary_hits_per_path"] / max(sm["segments_per_path"], 1e-9)
-            else:
-                n_node = (counters["boxTests"] + counters["rootVisits"]) / counters["segments"]
-                n_tri = counters["triTests"] / counters["segments"]
-                p_hit = counters["hits"] / counters["segments"]
-                kernel_seg = float(seg)
-                paths_per_seg = 1.0 / mean_len
+            # the bounces whose segments the timed kernel traces: [lo, hi)
+            lo = 1 if packets else 0
+            hi = args.bounces
+            if used_pipeline == 0:  # the wavefront organisation hands the late bounces to one persistent launch
+                tail = int(os.environ.get("LPT_WAVEFRONT_TAIL", "4"))
+                if 1 <= tail < args.bounces:
+                    hi = tail
+            upto_hi = counters if hi == args.bounces else traversal_counters(scene, ubos, args.width, args.height, hi)
+            upto_lo = traversal_counters(scene, ubos, args.width, args.height, lo) if lo > 0 else None
+            rm = range_means(upto_hi, upto_lo)
+            n_node = rm["boxTests"] + rm["rootVisits"]
+            n_tri, p_hit = rm["triTests"], rm["hits"]
+            kernel_seg = float(kernel_seg_total)
+            # paths that enter the kernel, per camera path: every camera path at bounce 0, else the first hits
+            # that went on (only lo = 1 occurs with per-path bytes: the hybrid organisation)
+            entering = 1.0 if lo == 0 else upto_lo["hits"] / max(upto_lo["paths"], 1)
+            paths_per_seg = entering / max(rm["segments_per_path"], 1e-9)
             if kernel == "k_extend":
                 state_bytes = 24.0 + 12.0
                 state_note = "36 B ray/hit"
@@ -304,8 +308,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "hbm_measured_gbs": (traffic / avg_s / 1e9) if traffic else None,
                 "note": f"achieved = algorithmic bytes (48 B/node fetched + 36 B/triangle + {state_note}) x the segments "
-                        f"{kernel} traced" + (" (all but the camera rays, which the packet kernel k_primary traces)"
-                                              if packets else "")
+                        f"{kernel} traced (bounces {lo} to {hi - 1})"
                         + f" / {kernel} time; the scene is cache-resident, so measured HBM traffic is far lower and "
                         "the kernel is bound by the L1 gather path and vector issue, not by HBM",
                 "bytes_per_segment": bytes_per_seg, "nodes_per_segment": n_node, "tris_per_segment": n_tri,

@@ -121,6 +121,7 @@ typedef struct lpt_stats {
                              (wavefront; the camera rays' packet kernel is not among them) or k_trace */
   uint32_t extend_launches;
   uint32_t pipeline;      /* organisation the call ran with (what LPT_PIPELINE_AUTO resolved to) */
+  uint64_t kernel_segments; /* the segments traced by the launches that extend_ms times */
 } lpt_stats;
 
 /* ---- context ---------------------------------------------------------------- */

@@ -42,6 +42,7 @@ static_assert(offsetof(lpt_ubo, seed) == 80 && offsetof(lpt_ubo, reset) == 88, "
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kTotalsWords = 24;  // [0] paths, [1] segments, [2..15] analysis builds, [16] segments of timed launches
 
 // Path queue, Structure of Arrays; slot i of each array belongs to one path.
 // The radiance a path has gathered does not travel with it: it lives in samples[path id], which
@@ -302,13 +303,19 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Partition P, const lpt_ub
   }
 }
 
-// totals[0] += paths started, totals[1] += ray segments traced (queue fills per bounce).
-__global__ void k_tally(const uint32_t* __restrict__ counts, uint32_t nBounces, unsigned long long* totals) {
+// totals[0] += paths started, totals[1] += ray segments traced (queue fills per bounce), totals[16] += those
+// of the bounces from `timedFrom` on (the ones whose extend launches are timed).
+__global__ void k_tally(const uint32_t* __restrict__ counts, uint32_t nBounces, uint32_t timedFrom,
+                        unsigned long long* totals) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    unsigned long long seg = 0;
-    for (uint32_t b = 0; b < nBounces; ++b) seg += counts[b];
+    unsigned long long seg = 0, timed = 0;
+    for (uint32_t b = 0; b < nBounces; ++b) {
+      seg += counts[b];
+      if (b >= timedFrom) timed += counts[b];
+    }
     totals[0] += counts[0];
     totals[1] += seg;
+    totals[16] += timed;
   }
 }
 
@@ -796,6 +803,9 @@ void launch_shade(lpt_ctx* c, const Queue& in, const Queue& out, uint32_t b, uin
                      c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
 }
 
+template <bool QUEUED>
+void dispatch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src);
+
 int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   int rc = ensure_pool(c, frames);
   if (rc) return rc;
@@ -813,7 +823,11 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
                        (uint32_t)frames, c->queues[0], c->dValidBefore, c->nValid);
   rc = ensure_events(c, c->evUsed + 2 * (size_t)nB);
   if (rc) return rc;
-  for (uint32_t b = 0; b < nB; ++b) {
+  // From bounce `tail` on the queues are short (Russian roulette thins them out from bounce 3) and a launch
+  // per bounce costs more in tails than it does work: one persistent launch finishes those paths.
+  static const uint32_t tailFrom = std::getenv("LPT_WAVEFRONT_TAIL") ? (uint32_t)std::atoi(std::getenv("LPT_WAVEFRONT_TAIL")) : 4u;
+  const uint32_t tail = tailFrom >= 1u && tailFrom < nB ? tailFrom : nB;
+  for (uint32_t b = 0; b < tail; ++b) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
     if (b == 0 && primary_packets() && primary_fused()) {
@@ -829,9 +843,15 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
     }
     launch_shade(c, in, out, b, nB, paths);
   }
+  if (tail < nB) {
+    const Queue& q = c->queues[tail & 1];
+    dispatch_trace<true>(c, frames, cursors + (size_t)tail * kCursorRegions,
+                         TraceQueue{q.o, q.d, q.m, c->dCounts + tail, tail, 0u});
+  }
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
-  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, nB, c->dTotals);
+  // segments of the bounces run here; the persistent launch has added those it traced
+  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, tail, primary_packets() ? 1u : 0u, c->dTotals);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -875,7 +895,7 @@ int render_batch_persistent(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   rc = ensure_events(c, c->evUsed + 2);
   if (rc) return rc;
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-  dispatch_trace<false>(c, frames, c->dCounts, TraceQueue{nullptr, nullptr, nullptr, nullptr});
+  dispatch_trace<false>(c, frames, c->dCounts, TraceQueue{nullptr, nullptr, nullptr, nullptr, 0u, 1u});
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
@@ -916,12 +936,12 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   }
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   if (nB > 1 && c->nValid)
-    dispatch_trace<true>(c, frames, cursors + kCursorRegions, TraceQueue{q1.o, q1.d, q1.m, c->dCounts + 1});
+    dispatch_trace<true>(c, frames, cursors + kCursorRegions, TraceQueue{q1.o, q1.d, q1.m, c->dCounts + 1, 1u, 1u});
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
   // camera paths and their segments; the persistent launch has added the segments it traced
-  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, 1u, c->dTotals);
+  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, 1u, 1u, c->dTotals);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -1031,8 +1051,8 @@ int lpt_create(int device, lpt_ctx** out) {
   c->stream = c->ownStream;
   if ((e = hipEventCreate(&c->evStart)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->evStop)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&c->dTotals, 16 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMemset(c->dTotals, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipMalloc(&c->dTotals, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   *out = c;
   return LPT_OK;
 }
@@ -1366,7 +1386,7 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   c->evUsed = 0;
   c->haveTiming = false;
-  LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, 16 * sizeof(unsigned long long), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long), c->stream));
   LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
   if (c->pipeline == LPT_PIPELINE_MEGAKERNEL) {
     c->activePipeline = LPT_PIPELINE_MEGAKERNEL;
@@ -1432,7 +1452,7 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   std::memset(out, 0, sizeof *out);
   if (!c->haveTiming) return fail(c, LPT_ERR_INVALID, "nothing rendered yet");
   LPT_HIP(c, hipStreamSynchronize(c->stream));
-  unsigned long long totals[2] = {0, 0};
+  unsigned long long totals[kTotalsWords] = {};
   LPT_HIP(c, hipMemcpy(totals, c->dTotals, sizeof totals, hipMemcpyDeviceToHost));
 #ifdef LPT_EXTEND_STATS
   {
@@ -1459,6 +1479,7 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
 #endif
   out->paths = totals[0];
   out->segments = totals[1];
+  out->kernel_segments = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? totals[1] : totals[16];
   out->frames = c->lastFrames;
   float ms = 0.0f;
   LPT_HIP(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));

@@ -48,16 +48,19 @@ struct TraceShared {
 };
 
 // Where the paths of a launch come from when QUEUED: entries [0, *count) of a path queue (origin | path-id
-// word, direction | rng.x, throughput | rng.y) written by the shading of the camera rays' hits; such paths
-// start at bounce 1.
+// word, direction | rng.x, throughput | rng.y) written by the shading kernel of bounce `bounce` - 1; the
+// paths go on from bounce `bounce`.
 struct TraceQueue {
   const float4* o;
   const float4* d;
   const float4* m;
   const uint32_t* count;
+  uint32_t bounce;
+  uint32_t timed;  // this launch is the one whose time the statistics report: its segments go to totals[16] too
 };
 
-// `cursor` holds kCursorRegions zeroed words; `totals[0]` counts paths, `totals[1]` ray segments
+// `cursor` holds kCursorRegions zeroed words; `totals[0]` counts paths, `totals[1]` ray segments, `totals[16]`
+// the segments of timed launches
 // (QUEUED: only the segments traced here are added).
 template <int S, int BLOCK, bool QUEUED>
 __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partition& P,
@@ -248,7 +251,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
                   const float4 g = samples[pid];
                   p.acc = f3{g.x, g.y, g.z};
                 }
-                bounce = 1;
+                bounce = src.bounce;
                 ++nPaths;
                 startSearch = true;
               } else {
@@ -419,6 +422,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
   if (lane == 0 && nPaths) {
     if (!QUEUED) atomicAdd(&totals[0], (unsigned long long)nPaths);
     atomicAdd(&totals[1], (unsigned long long)nSegments);
+    if (src.timed) atomicAdd(&totals[16], (unsigned long long)nSegments);
   }
 #ifdef LPT_TRACE_STATS
   if (lane == 0)
