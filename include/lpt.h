@@ -90,10 +90,11 @@ typedef enum lpt_status {
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
 /* Kernel organisation; all produce identical pixels.
- * AUTO (default): HYBRID; WAVEFRONT for batches of about 100 Mi paths and more on a scene that
- *            stays in cache; PERSISTENT when the ray queues do not fit in device memory.
+ * AUTO (default): HYBRID; WAVEFRONT for batches of about 100 Mi paths and more; PERSISTENT when
+ *            the ray queues do not fit in device memory.
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (128 bytes of
- *            queues per path in flight); camera rays are traced as packets.
+ *            queues per path in flight); the first segment runs in the packet kernel, bounces
+ *            from the fourth on in one persistent launch.
  * MEGAKERNEL: one thread per pixel runs the whole path (the shader's own organisation).
  * PERSISTENT: one launch per batch, paths stay in registers from the camera ray on (16 bytes
  *            per path in flight).

@@ -1399,20 +1399,19 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     int fif = std::min(auto_frames_in_flight(c), n_frames);
     // path ids of a batch must leave bit 31 free (kAccStored)
     fif = std::max(1, std::min<int>(fif, (int)(0x7FFFFFFFu / std::max<uint32_t>(c->part.nSlots, 1u))));
-    // AUTO.  All organisations trace the camera rays as packets when they have queues.  After that:
-    //  - HYBRID (one persistent launch for everything beyond the camera rays) has no per-bounce launches
-    //    and tails: best for small and medium batches (Cornell box 1080p, one frame: 3.3x the wavefront
-    //    kernels) and, at any batch size, for scenes beyond an XCD's 4 MiB L2;
-    //  - WAVEFRONT (one extend and one shade launch per bounce) keeps seven waves per SIMD in the search
-    //    and full waves in shading: ahead once a batch is large enough to amortise its launches (from
-    //    about 100 Mi paths) on a scene that stays in cache (Cornell box: +1 % at 128 Mi paths, +6 % at 256 Mi);
-    //  - PERSISTENT (no queues, 16 instead of 128 bytes per path in flight) when the queues do not fit.
+    // AUTO.  The first segment of every path runs in the packet kernel whenever there are queues.  After that:
+    //  - HYBRID (one persistent launch for everything beyond the first segment) has no per-bounce launches
+    //    and tails: best for small and medium batches (Cornell box 1080p, one frame: 3.4x the wavefront
+    //    kernels);
+    //  - WAVEFRONT (one extend and one shade launch per bounce up to bounce 3, the thinned-out rest in one
+    //    persistent launch) keeps seven waves per SIMD in the search and full waves in shading: ahead once
+    //    a batch is large enough to amortise its launches, from about 100 Mi paths (Cornell box: +4 % at
+    //    128 Mi paths, +8 % at 256 Mi; a 400 k-triangle scene: +1 %);
+    //  - PERSISTENT (no queues, 16 instead of 64 / 128 bytes per path in flight) when the queues do not fit.
     c->activePipeline = c->pipeline;
     if (c->pipeline == LPT_PIPELINE_AUTO) {
-      const double traversalBytes = 64.0 * c->nNodes + 48.0 * c->nTris;
-      const bool largeScene = traversalBytes > 4.0 * 1024 * 1024;
       const bool largeBatch = (double)fif * c->part.nSlots >= 96.0 * 1024 * 1024;
-      c->activePipeline = largeBatch && !largeScene ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_HYBRID;
+      c->activePipeline = largeBatch ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_HYBRID;
     }
     rc = ensure_pool(c, fif);
     if (rc == LPT_ERR_NOMEM && c->pipeline == LPT_PIPELINE_AUTO) {
