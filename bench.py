@@ -291,6 +291,7 @@ def main():
             # HBM bytes per launch: PMC measurement of this workload (profiles/*_traffic.json holds bytes
             # and segments per launch of the profiled run), scaled to this run's segments per launch
             traffic = None
+            units = None
             tpath = os.path.join(ROOT, "profiles", {"k_extend": "extend_traffic.json", "k_trace": "trace_traffic.json"}
                                  .get(kernel, "none"))
             default_workload = (os.path.basename(args.scene) == "cornell_box.gltf" and args.bounces == 8
@@ -299,6 +300,7 @@ def main():
                 try:
                     t = json.load(open(tpath))
                     if t.get("pipeline", used_pipeline) == used_pipeline:
+                        units = t.get("units")
                         traffic = t["hbm_bytes_per_launch"] / t["segments_per_launch"] * kernel_seg / max(ext_launches, 1)
                 except Exception:
                     traffic = None
@@ -313,6 +315,8 @@ def main():
                         "the kernel is bound by the L1 gather path and vector issue, not by HBM",
                 "bytes_per_segment": bytes_per_seg, "nodes_per_segment": n_node, "tris_per_segment": n_tri,
                 "hits_per_segment": p_hit,
+                # busy fractions of the units that do bound the kernel, from the committed PMC passes of this workload
+                "measured_unit_busy": units,
                 "avg_launch_ms": ext_ms / max(ext_launches, 1), "launches": ext_launches,
                 "segments_per_launch": kernel_seg / max(ext_launches, 1),
             }

@@ -63,6 +63,18 @@ for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_tr
         pipe = {"wavefront": 0, "persistent": 2, "hybrid": 4}.get(b["config"]["pipeline"].split()[0])
     except Exception:
         pass
+    # how busy the units that actually bound the kernel were: texture addresser / data return (the L1
+    # gather path, counters summed over 256 CUs) and vector issue (4 cycles per wave64 instruction on each
+    # of 1024 SIMDs), against the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    busy = {}
+    cyc, _ = per_dispatch("GRBM_GUI_ACTIVE", kernel)
+    if cyc:
+        cyc /= 8.0
+        for name, counter, scale in (("ta_busy_frac", "TA_TA_BUSY_sum", 1.0 / 256), ("td_busy_frac", "TD_TD_BUSY_sum", 1.0 / 256),
+                                     ("valu_issue_frac", "SQ_INSTS_VALU", 4.0 / 1024)):
+            v, _ = per_dispatch(counter, kernel)
+            if v is not None:
+                busy[name] = v * scale / cyc
     traffic = {
         "kernel": kernel,
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
@@ -71,6 +83,7 @@ for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_tr
         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
         "segments_per_launch": segs,
         "pipeline": pipe,
+        "units": busy,
         "rule": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B reads as 64 B)",
     }
     json.dump(traffic, open(os.path.join(dst, fname), "w"), indent=1)
