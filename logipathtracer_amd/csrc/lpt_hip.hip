@@ -135,23 +135,132 @@ __global__ __launch_bounds__(kBlock) void k_primary(const TNode* __restrict__ no
   primary_packet<true>(nodes, tris, otrav, rootRef, P, ubos, nFrames, validBefore, nValid, q, hits, p, hit, valid, pid);
 }
 
-// Shades queue entry i (a ray that hit something), samples the next direction, applies Russian
-// roulette.  Returns true if the path goes on (p, pidWord are what to queue); the radiance of a
-// finished path is in samples[path id].
-__device__ __forceinline__ bool shade_entry(const DScene& sc, const Queue& in, const float4* __restrict__ hits,
-                                            uint32_t i, float4* __restrict__ samples, uint32_t bounce,
-                                            uint32_t maxBounces, int bsdfMode, Path& p, uint32_t& pidWord) {
-  const float4 o = in.o[i], d = in.d[i], m = in.m[i], h = hits[i];
-  p.o = f3{o.x, o.y, o.z};
-  p.d = f3{d.x, d.y, d.z};
-  p.mask = f3{m.x, m.y, m.z};
-  p.acc = f3{0.0f, 0.0f, 0.0f};  // shade_hit leaves this bounce's emitted radiance here (0 + mask*emission)
-  p.rng = Rng{as_uint(d.w), as_uint(m.w)};
-  pidWord = as_uint(o.w);
+// ---- Heitz walks of a whole workgroup ---------------------------------------------------
+// The random walks of a block's hits differ widely in length on rough materials (1 to 16 orders), so
+// a loop per lane leaves most of a wave idle while its longest walk finishes.  Here every lane takes
+// the first kWalkInlineSteps orders of its own walk; walks still going are parked in LDS as jobs and
+// taken up again by the lowest threads of the block, kWalkPassSteps orders per pass, the list of
+// unfinished jobs being compacted between passes: the waves that work are full.  A job carries
+// everything a step needs, the arithmetic and random numbers are those of heitz_bsdf_unified.
+#ifndef LPT_WALK_INLINE_STEPS
+#define LPT_WALK_INLINE_STEPS 2
+#endif
+#ifndef LPT_WALK_PASS_STEPS
+#define LPT_WALK_PASS_STEPS 2
+#endif
+constexpr int kWalkJobWords = 16;  // lightDir 0-2, energy 3-5, height 6, order|outside|kind 7, rng 8-9, F0 10-12, alpha, iorOut, iorIn
+
+struct WalkShared {
+  float job[kWalkJobWords][kBlock];  // field-major: lanes of a wave touch consecutive words
+  uint32_t list[2][kBlock];
+  uint32_t waveCount[kBlock / 64];
+};
+
+// Block-wide compaction: the threads with `flag` write `value` to consecutive entries of `out`; returns
+// how many there are (the same number in every thread).  Synchronises the block.
+__device__ __forceinline__ uint32_t walk_compact(bool flag, uint32_t value, uint32_t* out, uint32_t* waveCount) {
+  const unsigned long long b = __ballot(flag);
+  const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+  const uint32_t wave = threadIdx.x >> 6;
+  __syncthreads();  // readers of the previous list and counts are done
+  if ((threadIdx.x & 63u) == 0u) waveCount[wave] = (uint32_t)__popcll(b);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (uint32_t w = 0; w < kBlock / 64; ++w) {
+    const uint32_t k = waveCount[w];
+    if (w < wave) before += k;
+    total += k;
+  }
+  if (flag) out[before + below] = value;
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ void walk_store(WalkShared& ws, uint32_t j, const HeitzWalk& w, const Rng& rng) {
+  ws.job[0][j] = w.lightDir.x;
+  ws.job[1][j] = w.lightDir.y;
+  ws.job[2][j] = w.lightDir.z;
+  ws.job[3][j] = w.energy.x;
+  ws.job[4][j] = w.energy.y;
+  ws.job[5][j] = w.energy.z;
+  ws.job[6][j] = w.height;
+  ws.job[8][j] = as_float(rng.x);
+  ws.job[9][j] = as_float(rng.y);
+}
+
+// Samples the Heitz BSDF for every thread with `walking` (all threads of the block must call).
+__device__ __forceinline__ void walk_block(WalkShared& ws, bool walking, Rng& rng, const Surface& sf, f3& weight,
+                                           f3& lightDir) {
+  const uint32_t t = threadIdx.x;
+  const float alpha = sf.roughness * sf.roughness;
+  const float iorOut = sf.outside ? 1.0f : sf.ior;
+  const float iorIn = sf.outside ? sf.ior : 1.0f;
+  HeitzWalk w;
+  heitz_walk_begin(w, sf.viewDir);
+  bool parked = false;
+  if (walking) {
+    bool done = false;
+    for (int k = 0; k < LPT_WALK_INLINE_STEPS && !done; ++k)
+      done = heitz_walk_step(rng, w, sf.interaction, sf.baseLinear, alpha, iorOut, iorIn);
+    if (done) {
+      weight = heitz_walk_result(w, sf.interaction, sf.baseLinear, lightDir);
+    } else {
+      parked = true;
+      walk_store(ws, t, w, rng);
+      ws.job[7][t] = as_float((uint32_t)w.order | (w.outside ? 0x100u : 0u) | (sf.interaction << 9));
+      ws.job[10][t] = sf.baseLinear.x;
+      ws.job[11][t] = sf.baseLinear.y;
+      ws.job[12][t] = sf.baseLinear.z;
+      ws.job[13][t] = alpha;
+      ws.job[14][t] = iorOut;
+      ws.job[15][t] = iorIn;
+    }
+  }
+  int cur = 0;
+  uint32_t n = walk_compact(parked, t, ws.list[0], ws.waveCount);
+  while (n > 0u) {  // n is the same in every thread
+    bool still = false;
+    uint32_t j = 0;
+    if (t < n) {
+      j = ws.list[cur][t];
+      HeitzWalk jw;
+      jw.lightDir = f3{ws.job[0][j], ws.job[1][j], ws.job[2][j]};
+      jw.energy = f3{ws.job[3][j], ws.job[4][j], ws.job[5][j]};
+      jw.height = ws.job[6][j];
+      const uint32_t packed = as_uint(ws.job[7][j]);
+      jw.order = (int)(packed & 0xFFu);
+      jw.outside = (packed & 0x100u) != 0u;
+      const uint32_t kind = packed >> 9;
+      Rng jr{as_uint(ws.job[8][j]), as_uint(ws.job[9][j])};
+      const f3 F0{ws.job[10][j], ws.job[11][j], ws.job[12][j]};
+      const float ja = ws.job[13][j], jo = ws.job[14][j], ji = ws.job[15][j];
+      bool done = false;
+      for (int k = 0; k < LPT_WALK_PASS_STEPS && !done; ++k) done = heitz_walk_step(jr, jw, kind, F0, ja, jo, ji);
+      if (done) {  // result in place of the walk: weight over the energy, direction over the direction
+        f3 ld;
+        const f3 wt = heitz_walk_result(jw, kind, F0, ld);
+        jw.lightDir = ld;
+        jw.energy = wt;
+      } else {
+        still = true;
+        ws.job[7][j] = as_float((uint32_t)jw.order | (jw.outside ? 0x100u : 0u) | (kind << 9));
+      }
+      walk_store(ws, j, jw, jr);
+    }
+    n = walk_compact(still, j, ws.list[cur ^ 1], ws.waveCount);
+    cur ^= 1;
+  }
+  if (parked) {
+    lightDir = f3{ws.job[0][t], ws.job[1][t], ws.job[2][t]};
+    weight = f3{ws.job[3][t], ws.job[4][t], ws.job[5][t]};
+    rng = Rng{as_uint(ws.job[8][t]), as_uint(ws.job[9][t])};
+  }
+}
+
+// Bookkeeping of a shaded queue entry: the radiance this bounce emitted joins what the path has gathered
+// in samples[path id]; a path that ends without ever having gathered anything leaves zero there.
+__device__ __forceinline__ void settle_entry(float4* __restrict__ samples, const Path& p, uint32_t& pidWord, bool alive) {
   const uint32_t slot = pidWord & ~kAccStored;
-  const Hit hit{h.x, as_uint(h.y), as_uint(h.z)};
-  f3 s;
-  const bool alive = shade_hit<true>(sc, p, hit, bounce, maxBounces, bsdfMode, s);
   if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
     // gathered + mask*emission, path_tracing.comp:269 (adding a zero product would change nothing)
     f3 acc = p.acc;
@@ -164,7 +273,6 @@ __device__ __forceinline__ bool shade_entry(const DScene& sc, const Queue& in, c
   } else if (!alive && !(pidWord & kAccStored)) {
     samples[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the path ends without having gathered anything
   }
-  return alive;
 }
 
 // The lobe a hit on this object will most likely sample (0 diffuse, 1 conductor, 2 dielectric):
@@ -189,16 +297,39 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
   __shared__ uint32_t lds[kBlock / 64 + 1];
   __shared__ uint32_t waveCount[kShadeClasses][kBlock / 64];
   __shared__ uint32_t pending[kShadeClasses][2 * kBlock];  // fewer than kBlock entries each between scans
+  __shared__ WalkShared walk;
   const uint32_t n = *countIn;
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t nPending[kShadeClasses] = {0u, 0u, 0u};  // same values in every thread of the block
 
-  auto shade_list = [&](int c, uint32_t count) {  // the first min(count, kBlock) entries of list c; called by all threads
-    bool alive = false;
+  // Shades the first min(count, kBlock) entries of list c (rays that hit something): the hit, the BSDF sample
+  // (the Heitz walks of the block together, see walk_block), Russian roulette; called by all threads.
+  auto shade_list = [&](int c, uint32_t count) {
+    bool began = false, alive = false;
     Path p;
+    Surface sf;
     uint32_t pidWord = 0;
-    if (threadIdx.x < count)
-      alive = shade_entry(sc, in, hits, pending[c][threadIdx.x], samples, bounce, maxBounces, bsdfMode, p, pidWord);
+    f3 sample{0.0f, 0.0f, 0.0f}, weight{0.0f, 0.0f, 0.0f}, lightDir{0.0f, 0.0f, 0.0f};
+    if (threadIdx.x < count) {
+      const uint32_t i = pending[c][threadIdx.x];
+      const float4 o = in.o[i], d = in.d[i], m = in.m[i], h = hits[i];
+      p.o = f3{o.x, o.y, o.z};
+      p.d = f3{d.x, d.y, d.z};
+      p.mask = f3{m.x, m.y, m.z};
+      p.acc = f3{0.0f, 0.0f, 0.0f};  // shade_begin leaves this bounce's emitted radiance here (0 + mask*emission)
+      p.rng = Rng{as_uint(d.w), as_uint(m.w)};
+      pidWord = as_uint(o.w);
+      began = shade_begin(sc, p, Hit{h.x, as_uint(h.y), as_uint(h.z)}, sf, sample);
+    }
+    if (bsdfMode == LPT_BSDF_HEITZ) {
+      walk_block(walk, began, p.rng, sf, weight, lightDir);
+    } else if (began) {
+      weight = basic_bsdf(p.rng, sf, lightDir);
+    }
+    if (began) {
+      alive = shade_end(p, sf, weight, lightDir, bounce, maxBounces, sample);
+      settle_entry(samples, p, pidWord, alive);
+    }
     const uint32_t carry = threadIdx.x + kBlock < count ? pending[c][threadIdx.x + kBlock] : 0u;
     const uint32_t dst = block_append(alive, countOut, lds);  // synchronises the block
     if (alive) store_path(out, dst, p, pidWord);
@@ -259,17 +390,25 @@ __global__ __launch_bounds__(kBlock) void k_primary_shade(const TNode* __restric
                                                           uint32_t* countOut, float4* __restrict__ samples,
                                                           uint32_t maxBounces, int bsdfMode) {
   __shared__ uint32_t lds[kBlock / 64 + 1];
+  __shared__ WalkShared walk;
   Path p;
   Hit hit;
   bool valid;
   uint32_t pid;
   primary_packet<false>(nodes, tris, otrav, sc.rootRef, P, ubos, nFrames, nullptr, 0u, PrimaryQueue{nullptr, nullptr, nullptr},
                         nullptr, p, hit, valid, pid);
-  bool alive = false;
+  bool alive = false, began = false;
   uint32_t pidWord = pid;
+  Surface sf;
+  f3 s{0.0f, 0.0f, 0.0f}, weight{0.0f, 0.0f, 0.0f}, lightDir{0.0f, 0.0f, 0.0f};
+  if (valid) began = shade_begin(sc, p, hit, sf, s);  // a miss ends the path with s = 0.2 * throughput
+  if (bsdfMode == LPT_BSDF_HEITZ) {
+    walk_block(walk, began, p.rng, sf, weight, lightDir);
+  } else if (began) {
+    weight = basic_bsdf(p.rng, sf, lightDir);
+  }
+  if (began) alive = shade_end(p, sf, weight, lightDir, 0u, maxBounces, s);
   if (valid) {
-    f3 s{0.0f, 0.0f, 0.0f};
-    alive = shade_hit<true>(sc, p, hit, 0u, maxBounces, bsdfMode, s);  // a miss ends the path with s = 0.2 * throughput
     if (hit.t == kInfinity) {
       samples[pid] = make_float4(s.x, s.y, s.z, 0.0f);
     } else if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
