@@ -187,16 +187,21 @@ __device__ __forceinline__ void heitz_walk_begin(HeitzWalk& w, f3 viewDir) {
   w.outside = true;
 }
 
-// One scattering order: the body of the `for (order ...)` loops of heitz/BSDF.glsl:116-135,
-// :183-206 and :249-266.  Returns true when the walk is over (it left the microsurface or
-// reached the order cap).  iorOut/iorIn are the indices on the ray's side / the far side.
-__device__ __forceinline__ bool heitz_walk_step(Rng& rng, HeitzWalk& w, uint32_t kind, f3 F0, float alpha,
-                                                float iorOut, float iorIn) {
+// One scattering order — the body of the `for (order ...)` loops of heitz/BSDF.glsl:116-135, :183-206
+// and :249-266 — in its two halves, so that kernels may schedule them separately:
+//   heitz_walk_height: the next intersection with the microsurface; true if the walk left it (walk over);
+//   heitz_walk_scatter: the scattering event there; true if the order cap is reached (walk over).
+// iorOut/iorIn are the indices on the ray's side / the far side.
+__device__ __forceinline__ bool heitz_walk_height(Rng& rng, HeitzWalk& w, uint32_t kind, float alpha) {
   const bool flip = (kind == kTrans) && !w.outside;
   const f3 dirH = flip ? -w.lightDir : w.lightDir;
   const float hs = sample_ggx_height(rng, dirH, flip ? -w.height : w.height, alpha);
   w.height = flip ? -hs : hs;
-  if (flip ? (w.height < 0.0f) : (w.height > 0.0f)) return true;
+  return flip ? (w.height < 0.0f) : (w.height > 0.0f);
+}
+
+__device__ __forceinline__ bool heitz_walk_scatter(Rng& rng, HeitzWalk& w, uint32_t kind, f3 F0, float alpha,
+                                                   float iorOut, float iorIn) {
   const f3 vd = -w.lightDir;
   const f3 m = sample_ggx_vndf(rng, vd, alpha);
   if (kind == kMetallic) {
@@ -239,6 +244,13 @@ __device__ __forceinline__ bool heitz_walk_step(Rng& rng, HeitzWalk& w, uint32_t
   }
   ++w.order;
   return w.order >= kHeitzMaxOrder;
+}
+
+// One whole order.  Returns true when the walk is over (it left the microsurface or reached the order cap).
+__device__ __forceinline__ bool heitz_walk_step(Rng& rng, HeitzWalk& w, uint32_t kind, f3 F0, float alpha,
+                                                float iorOut, float iorIn) {
+  if (heitz_walk_height(rng, w, kind, alpha)) return true;
+  return heitz_walk_scatter(rng, w, kind, F0, alpha, iorOut, iorIn);
 }
 
 // Weight and sampled direction of a finished walk.

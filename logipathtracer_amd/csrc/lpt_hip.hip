@@ -136,15 +136,15 @@ __global__ __launch_bounds__(kBlock) void k_primary(const TNode* __restrict__ no
 }
 
 // ---- Heitz walks of a whole workgroup ---------------------------------------------------
-// The random walks of a block's hits differ widely in length on rough materials (1 to 16 orders), so
-// a loop per lane leaves most of a wave idle while its longest walk finishes.  Here every lane takes
-// the first kWalkInlineSteps orders of its own walk; walks still going are parked in LDS as jobs and
-// taken up again by the lowest threads of the block, kWalkPassSteps orders per pass, the list of
-// unfinished jobs being compacted between passes: the waves that work are full.  A job carries
-// everything a step needs, the arithmetic and random numbers are those of heitz_bsdf_unified.
-#ifndef LPT_WALK_INLINE_STEPS
-#define LPT_WALK_INLINE_STEPS 2
-#endif
+// The random walks of a block's hits differ widely in length on rough materials (1 to 16 orders), and
+// within an order most of the work (the scattering event) is only done by the walks that have not just
+// left the microsurface: a loop per lane leaves most of a wave idle.  Here every lane takes the start of
+// its own walk — height, scattering, height: where most walks on smooth materials end — and walks still
+// going are parked in LDS as jobs.  A job is a walk that is about to scatter; the lowest threads of the
+// block take the jobs up, LPT_WALK_PASS_STEPS times (scatter, next height) per pass, and the list of
+// unfinished jobs is compacted between passes: the waves that work are full and their lanes in step.
+// A job carries everything a step needs; the operations and random numbers of a walk are those of
+// heitz_bsdf_unified in the same order.
 #ifndef LPT_WALK_PASS_STEPS
 #define LPT_WALK_PASS_STEPS 2
 #endif
@@ -199,15 +199,16 @@ __device__ __forceinline__ void walk_block(WalkShared& ws, bool walking, Rng& rn
   heitz_walk_begin(w, sf.viewDir);
   bool parked = false;
   if (walking) {
-    bool done = false;
-    for (int k = 0; k < LPT_WALK_INLINE_STEPS && !done; ++k)
-      done = heitz_walk_step(rng, w, sf.interaction, sf.baseLinear, alpha, iorOut, iorIn);
+    const uint32_t kind = sf.interaction;
+    bool done = heitz_walk_height(rng, w, kind, alpha);
+    if (!done) done = heitz_walk_scatter(rng, w, kind, sf.baseLinear, alpha, iorOut, iorIn);
+    if (!done) done = heitz_walk_height(rng, w, kind, alpha);
     if (done) {
-      weight = heitz_walk_result(w, sf.interaction, sf.baseLinear, lightDir);
-    } else {
+      weight = heitz_walk_result(w, kind, sf.baseLinear, lightDir);
+    } else {  // about to scatter again
       parked = true;
       walk_store(ws, t, w, rng);
-      ws.job[7][t] = as_float((uint32_t)w.order | (w.outside ? 0x100u : 0u) | (sf.interaction << 9));
+      ws.job[7][t] = as_float((uint32_t)w.order | (w.outside ? 0x100u : 0u) | (kind << 9));
       ws.job[10][t] = sf.baseLinear.x;
       ws.job[11][t] = sf.baseLinear.y;
       ws.job[12][t] = sf.baseLinear.z;
@@ -235,7 +236,10 @@ __device__ __forceinline__ void walk_block(WalkShared& ws, bool walking, Rng& rn
       const f3 F0{ws.job[10][j], ws.job[11][j], ws.job[12][j]};
       const float ja = ws.job[13][j], jo = ws.job[14][j], ji = ws.job[15][j];
       bool done = false;
-      for (int k = 0; k < LPT_WALK_PASS_STEPS && !done; ++k) done = heitz_walk_step(jr, jw, kind, F0, ja, jo, ji);
+      for (int k = 0; k < LPT_WALK_PASS_STEPS && !done; ++k) {
+        done = heitz_walk_scatter(jr, jw, kind, F0, ja, jo, ji);
+        if (!done) done = heitz_walk_height(jr, jw, kind, ja);
+      }
       if (done) {  // result in place of the walk: weight over the energy, direction over the direction
         f3 ld;
         const f3 wt = heitz_walk_result(jw, kind, F0, ld);
