@@ -98,7 +98,7 @@ enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
  * MEGAKERNEL: one thread per pixel runs the whole path (the shader's own organisation).
  * PERSISTENT: one launch per batch, paths stay in registers from the camera ray on (16 bytes
  *            per path in flight).
- * HYBRID:    camera rays through the wavefront kernels (packets, shading at full waves), then
+ * HYBRID:    the first segment of every path in the packet kernel (camera ray, hit, shading), then
  *            one persistent launch finishes the paths that go on (64 bytes per path in flight). */
 enum {
   LPT_PIPELINE_WAVEFRONT = 0,
