@@ -22,6 +22,10 @@ namespace lpt {
 #ifndef LPT_SURFACE_THRESHOLD
 #define LPT_SURFACE_THRESHOLD 40
 #endif
+// Queue-fed launches have no costly ray generation in their surface rounds: a lower threshold pays (+1 %).
+#ifndef LPT_SURFACE_THRESHOLD_QUEUED
+#define LPT_SURFACE_THRESHOLD_QUEUED 32
+#endif
 // New paths are started when at least this many lanes have none (or the wave has nothing else to do):
 // ray generation is costly and would otherwise run for a handful of lanes in every surface round.
 #ifndef LPT_NEW_MIN
@@ -126,7 +130,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     const int busy = nI + nT + nO;
     if (busy + nSurf == 0) break;
 
-    if (nSurf > 0 && (nSurf >= LPT_SURFACE_THRESHOLD || busy == 0)) {
+    if (nSurf > 0 && (nSurf >= (QUEUED ? LPT_SURFACE_THRESHOLD_QUEUED : LPT_SURFACE_THRESHOLD) || busy == 0)) {
       // ---- surface round ------------------------------------------------------------
       LPT_STAT(3, nSurf);
       bool finish = false;  // BSDF sampled: weight / lightDir are valid
