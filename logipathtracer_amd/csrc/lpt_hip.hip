@@ -388,6 +388,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
 // the shading of what it hit (as k_shade does for bounce 0, without the detour through a ray queue and a
 // hit array).  The pixels of a block mostly hit the same object, so the lanes shade in step without the
 // sorting k_shade does.  Paths that go on are appended to `out`.
+// Six waves per SIMD (80 VGPRs): the packet walk is a chain of dependent scalar loads and wants the waves
+// (measured: 4 waves -1.2 %, 5 as the compiler's own choice, 6 +0.7 % Cornell / +1.4 % rough terrain, 8 -0.5 %).
+#ifndef LPT_PRIMARY_WAVES_PER_SIMD
+#define LPT_PRIMARY_WAVES_PER_SIMD 6
+#endif
+__attribute__((amdgpu_waves_per_eu(LPT_PRIMARY_WAVES_PER_SIMD, LPT_PRIMARY_WAVES_PER_SIMD)))
 __global__ __launch_bounds__(kBlock) void k_primary_shade(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
                                                           const ObjTrav* __restrict__ otrav, DScene sc, Partition P,
                                                           const lpt_ubo* __restrict__ ubos, uint32_t nFrames, Queue out,
