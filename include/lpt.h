@@ -84,7 +84,11 @@ typedef enum lpt_status {
   LPT_ERR_UNSUPPORTED = -2, /* e.g. textured materials, BVH leaves too large to encode */
   LPT_ERR_STACK = -3,       /* BVH deeper than the traversal stack variants */
   LPT_ERR_HIP = -4,         /* a HIP runtime call failed; see lpt_last_error */
-  LPT_ERR_NOMEM = -5
+  LPT_ERR_NOMEM = -5,
+  LPT_ERR_TRUNCATED = -6    /* a persistent launch ran out of scheduling rounds with paths still in flight:
+                               the image of the last render is incomplete.  Reported by the next call that
+                               waits for the stream (lpt_synchronize, lpt_get_stats, lpt_read_accum,
+                               lpt_resolve, lpt_set_stream, the next lpt_render_frames), once. */
 } lpt_status;
 
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
@@ -153,6 +157,10 @@ typedef struct lpt_texture {
   uint32_t address_v;   /* note the reference passes wrappingW() here (:359) */
 } lpt_texture;
 #define LPT_MAX_TEXTURES 512u  /* sampler2D textures[512], shaders/path_tracing.comp:105 */
+/* Most primitives one BVH leaf may hold (triangles of a mesh-tree leaf, objects of an object-tree leaf):
+ * the traversal references of the device layer carry a 6-bit count.  lpt_upload_scene refuses larger
+ * leaves with LPT_ERR_UNSUPPORTED; builders must split them. */
+#define LPT_MAX_LEAF_PRIMITIVES 63u
 
 /* Replaces the texture half of the scene upload: copyTextureToGPU per material texture
  * (src/PTSceneConverter.cpp:69-84) and binding 6 of descriptor set 0
@@ -164,7 +172,11 @@ int lpt_upload_textures(lpt_ctx* ctx, const lpt_texture* textures, uint32_t n_te
 /* Replaces PTSceneConverter::copyToGPU x4 (src/PTSceneConverter.cpp:146-153) and
  * RendererPT::initializeAndBindSceneBuffer (src/RendererPT.cpp:433-509).  The
  * host arrays are copied; the caller keeps ownership.  Texture indices of the
- * objects (0xFFFFFFFF = none) must address textures uploaded before. */
+ * objects (0xFFFFFFFF = none) must address textures uploaded before.
+ * Objects may share a mesh tree only as instances, i.e. with equal bvhOffset AND equal
+ * verticesOffset; mesh-tree nodes reached from objects that differ in either are refused
+ * with LPT_ERR_UNSUPPORTED (the reference's converter never emits such buffers: every
+ * sub-mesh gets its own nodes and vertices, src/PTSceneConverter.cpp:87-120). */
 int lpt_upload_scene(lpt_ctx* ctx, const lpt_object* objects, uint32_t n_objects,
                      const lpt_bvh_node* object_bvh, uint32_t n_object_bvh,
                      const lpt_vertex* vertices, uint32_t n_vertices,
@@ -192,7 +204,10 @@ int lpt_set_options(lpt_ctx* ctx, int max_bounces, int bsdf_mode, int pipeline, 
 /* Renders n_frames consecutive frames (one sample per pixel each), frame i with
  * ubos[i]; equivalent to n_frames dispatches of path_tracing.comp::main
  * (shaders/path_tracing.comp:330-351) in order, including `reset` handling.
- * Asynchronous on the context's stream except for the copy of `ubos`. */
+ * The call first waits for the work of the previous call on this context (as
+ * RendererCore::drawFrame waits for its in-flight fence, src/RendererCore.cpp:376), then
+ * queues the new work on the context's stream and returns without waiting for it, unless
+ * n_frames exceeds the frames in flight: batches after the first wait for their predecessor. */
 int lpt_render_frames(lpt_ctx* ctx, const lpt_ubo* ubos, int n_frames);
 /* One frame; the call RendererPT::drawFrame lands on. */
 int lpt_render_frame(lpt_ctx* ctx, const lpt_ubo* ubo);
@@ -227,6 +242,10 @@ int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positions, uint32
                        lpt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* prim_order_out);
 
 /* ---- test hooks ---------------------------------------------------------------- */
+
+/* Caps the scheduling rounds a wave of the persistent kernels may run (0 restores the default of
+ * 2^24, far above any real batch), so that a test can provoke LPT_ERR_TRUNCATED. */
+int lpt_debug_set_trace_round_limit(lpt_ctx* ctx, uint32_t rounds);
 
 /* Evaluates one device math routine element-wise (op: 0 sin, 1 cos, 2 tan, 3 log,
  * 4 exp, 5 pow(a,b), 6 a/b, 7 sqrt, 8 srgb->linear); a, b, out are host arrays. */

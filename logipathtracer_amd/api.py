@@ -203,6 +203,10 @@ class Device:
         self._check(N.hip.lpt_build_mesh_bvh(self._ctx, 0, _ptr(corners), n, _ptr(nodes), C.byref(cnt), _ptr(order)))
         return nodes[:cnt.value].copy(), order[:n].copy()
 
+    def debug_set_trace_round_limit(self, rounds):
+        """Test hook: caps the scheduling rounds of the persistent kernels (0 = default)."""
+        self._check(N.hip.lpt_debug_set_trace_round_limit(self._ctx, int(rounds)))
+
     def debug_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)
         out = np.empty_like(a)

@@ -23,7 +23,8 @@ constexpr uint32_t kRefLeafBit = 0x80000000u;
 constexpr uint32_t kRefSentinel = 0xFFFFFFFFu;  // bottom of stack ("-1" in the shader)
 constexpr uint32_t kRefMarker = 0x7FFFFFFFu;    // end of an object's mesh tree
 constexpr uint32_t kRefFirstMask = 0x01FFFFFFu;
-constexpr uint32_t kMaxLeafCount = 63u;
+constexpr uint32_t kMaxLeafCount = LPT_MAX_LEAF_PRIMITIVES;
+static_assert(kMaxLeafCount == 63u, "leaf references carry a 6-bit count");
 constexpr uint32_t kMaxLeafFirst = 0x01FFFFFEu;
 
 __host__ __device__ inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) {

@@ -480,9 +480,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LPT_TRAC
 void k_trace(DScene sc, Partition P, const lpt_ubo* __restrict__ ubos,
                                                   uint32_t nFrames, uint32_t maxBounces, int bsdfMode,
                                                   float4* __restrict__ samples, uint32_t* cursor,
-                                                  unsigned long long* totals, TraceQueue src) {
+                                                  unsigned long long* totals, TraceQueue src, uint32_t* flags,
+                                                  uint32_t roundLimit) {
   __shared__ TraceShared<S, kBlock> sh;
-  trace_persistent<S, kBlock, QUEUED>(sc, P, ubos, nFrames, maxBounces, bsdfMode, samples, cursor, totals, sh, src);
+  trace_persistent<S, kBlock, QUEUED>(sc, P, ubos, nFrames, maxBounces, bsdfMode, samples, cursor, totals, sh, src, flags,
+                                      roundLimit);
 }
 
 // ---- megakernel --------------------------------------------------------------------
@@ -668,6 +670,12 @@ struct lpt_ctx {
   lpt_ubo* hUbos = nullptr;  // pinned staging
   int ubosCap = 0;
   unsigned long long* dTotals = nullptr;  // [0] paths, [1] segments
+  // Words the kernels raise when they give up: pinned host memory the device writes through its mapped
+  // address, so the host reads them after a stream synchronisation without a copy.
+  // [0]: a persistent launch reached its round limit with paths still in flight.
+  volatile uint32_t* hFlags = nullptr;
+  uint32_t* dFlags = nullptr;
+  uint32_t traceRoundLimit = LPT_TRACE_ROUND_LIMIT;
 
   // timing of the last lpt_render_frames call
   hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -690,6 +698,20 @@ int fail(lpt_ctx* ctx, int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                     \
       return fail(ctx, LPT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
   } while (0)
+
+// Every entry point that launches, copies or synchronises makes the context's GPU current first:
+// contexts on different GPUs may be used in turn from one thread.
+#define LPT_USE_DEVICE(ctx) LPT_HIP(ctx, hipSetDevice((ctx)->device))
+
+// After a stream synchronisation: did a kernel of the finished work give up?  The flag is consumed.
+int check_flags(lpt_ctx* c) {
+  if (c->hFlags && c->hFlags[0]) {
+    c->hFlags[0] = 0u;
+    return fail(c, LPT_ERR_TRUNCATED,
+                "a persistent launch reached its round limit with paths still in flight: the last render is incomplete");
+  }
+  return 0;
+}
 
 template <typename T>
 void dfree(T*& p) {
@@ -728,13 +750,24 @@ DScene device_scene(const lpt_ctx* c) {
 // returns the number of stack entries a traversal of it can hold at once; leafNeed(first,count)
 // gives what a leaf adds (and validates its range; negative = error code).  Iterative
 // post-order; rejects bad indices, cycles and leaves too large for a traversal reference.
+// `owner` records for every node the `tag` of the first tree that reached it: the derived arrays
+// hold one copy of a node (and of a leaf's triangles), so a node may only be shared by trees with
+// the same tag (mesh trees: the object's bvhOffset and verticesOffset packed into one word).
+constexpr uint64_t kNoOwner = ~0ull;
 template <typename LeafNeed>
 int tree_need(const lpt_bvh_node* nodes, uint32_t nNodes, uint32_t base, std::vector<int>& need, LeafNeed leafNeed,
-              std::string& err) {
+              std::string& err, std::vector<uint64_t>& owner, uint64_t tag) {
   if (base >= nNodes) {
     err = "BVH root index out of range";
     return LPT_ERR_INVALID;
   }
+  auto claim = [&](uint32_t i) -> bool {
+    if (owner[i] == kNoOwner) owner[i] = tag;
+    if (owner[i] == tag) return true;
+    err = "mesh BVH nodes are shared by objects that differ in bvhOffset or verticesOffset";
+    return false;
+  };
+  if (!claim(base)) return LPT_ERR_UNSUPPORTED;
   auto leaf = [&](const lpt_bvh_node& n) -> int {
     uint32_t first = n.indices[0], last = n.indices[1];
     uint32_t count = last > first ? last - first : 0u;
@@ -757,6 +790,7 @@ int tree_need(const lpt_bvh_node* nodes, uint32_t nNodes, uint32_t base, std::ve
       return LPT_ERR_INVALID;
     }
     uint32_t c[2] = {(uint32_t)c64[0], (uint32_t)c64[1]};
+    if (!claim(c[0]) || !claim(c[1])) return LPT_ERR_UNSUPPORTED;
     if (need[i] == -2) {
       need[i] = -1;
       bool pushed = false;
@@ -1021,7 +1055,8 @@ void launch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& sr
   const size_t need = (paths + kBlock - 1) / kBlock;
   const int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
   hipLaunchKernelGGL((k_trace<S, QUEUED>), dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), c->part, c->dUbos,
-                     (uint32_t)frames, (uint32_t)c->maxBounces, c->bsdfMode, c->dSamples, cursor, c->dTotals, src);
+                     (uint32_t)frames, (uint32_t)c->maxBounces, c->bsdfMode, c->dSamples, cursor, c->dTotals, src, c->dFlags,
+                     c->traceRoundLimit);
 }
 
 template <bool QUEUED>
@@ -1125,10 +1160,15 @@ int set_partition(lpt_ctx* c, int W, int H, int tileW, int tileH, int rank, int 
   if (slots >= (1ull << 31)) return fail(c, LPT_ERR_INVALID, "image too large for one context");
   P.nSlots = (uint32_t)slots;
   P.dense = (W % tileW == 0 && H % tileH == 0 && (P.tilesX * P.tilesY) % nRanks == 0) ? 1 : 0;
+  LPT_USE_DEVICE(c);
+  // nothing renders into a half-built image: the context counts as unsized until every buffer exists
+  c->sized = false;
+  c->part.nSlots = 0;
+  c->nValid = 0;
   dfree(c->dAccum);
   dfree(c->dImage);
   dfree(c->dValidBefore);
-  LPT_HIP(c, hipSetDevice(c->device));
+  free_pool(c);
   c->nValid = P.nSlots;
   if (!P.dense) {
     std::vector<uint32_t> before(P.nSlots);
@@ -1147,7 +1187,6 @@ int set_partition(lpt_ctx* c, int W, int H, int tileW, int tileH, int rank, int 
   LPT_HIP(c, hipMemsetAsync(c->dAccum, 0, slots * sizeof(float4), c->stream));
   c->part = P;
   c->sized = true;
-  free_pool(c);
   return 0;
 }
 
@@ -1202,6 +1241,13 @@ int lpt_create(int device, lpt_ctx** out) {
   if ((e = hipEventCreate(&c->evStop)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&c->dTotals, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  void* flags = nullptr;
+  if ((e = hipHostMalloc(&flags, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+    return bail("hipHostMalloc", e);
+  c->hFlags = static_cast<volatile uint32_t*>(flags);
+  for (int k = 0; k < 4; ++k) c->hFlags[k] = 0u;
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dFlags), flags, 0)) != hipSuccess)
+    return bail("hipHostGetDevicePointer", e);
   *out = c;
   return LPT_OK;
 }
@@ -1219,6 +1265,7 @@ void lpt_destroy(lpt_ctx* c) {
   dfree(c->dUbos);
   dfree(c->dTotals);
   if (c->hUbos) (void)hipHostFree(c->hUbos);
+  if (c->hFlags) (void)hipHostFree(const_cast<uint32_t*>(c->hFlags));
   for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
   if (c->evStart) (void)hipEventDestroy(c->evStart);
   if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -1230,9 +1277,10 @@ const char* lpt_last_error(const lpt_ctx* c) { return c ? c->err.c_str() : g_cre
 
 int lpt_set_stream(lpt_ctx* c, void* hip_stream) {
   if (!c) return LPT_ERR_INVALID;
+  LPT_USE_DEVICE(c);
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
-  return LPT_OK;
+  return check_flags(c);
 }
 
 int lpt_upload_textures(lpt_ctx* c, const lpt_texture* textures, uint32_t n) {
@@ -1294,6 +1342,7 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
 
   // 1. validate both levels and size the traversal stack
   std::vector<int> needB(nMeshBvh, -2);
+  std::vector<uint64_t> ownerB(nMeshBvh, kNoOwner);
   std::vector<int> objNeed(nObj, 0);
   for (uint32_t i = 0; i < nObj; ++i) {
     const uint32_t triBase = objects[i].verticesOffset / 3u;
@@ -1304,7 +1353,11 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
       }
       return 0;
     };
-    int need = tree_need(meshBvh, nMeshBvh, objects[i].bvhOffset, needB, triLeaf, err);
+    // Instances (objects with the same bvhOffset and verticesOffset) share a tree; anything else that
+    // reaches the same nodes is refused: child indices are relative to bvhOffset and triangles to
+    // verticesOffset (shaders/path_tracing.comp:149,160), so such objects would need their own copies.
+    const uint64_t tag = ((uint64_t)objects[i].bvhOffset << 32) | objects[i].verticesOffset;
+    int need = tree_need(meshBvh, nMeshBvh, objects[i].bvhOffset, needB, triLeaf, err, ownerB, tag);
     if (need < 0) return fail(c, need, err);
     objNeed[i] = need;
   }
@@ -1318,7 +1371,8 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
     for (uint32_t k = first; k < first + count; ++k) worst = std::max(worst, objNeed[k]);
     return (count > 1u ? 2 : 1) + worst;  // remaining-range entry + end-of-object marker
   };
-  int needScene = tree_need(objBvh, nObjBvh, 0, needT, objLeaf, err);
+  std::vector<uint64_t> ownerT(nObjBvh, kNoOwner);
+  int needScene = tree_need(objBvh, nObjBvh, 0, needT, objLeaf, err, ownerT, 0ull);
   if (needScene < 0) return fail(c, needScene, err);
   int stackNeed = needScene + 1;  // bottom-of-stack sentinel
   if (stackNeed > 64) return fail(c, LPT_ERR_STACK, "BVH needs a traversal stack deeper than 64 entries");
@@ -1498,6 +1552,7 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
 int lpt_resize(lpt_ctx* c, int width, int height) {
   if (!c) return LPT_ERR_INVALID;
   if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return fail(c, LPT_ERR_INVALID, "bad image size");
+  LPT_USE_DEVICE(c);
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   return set_partition(c, width, height, (width + 7) & ~7, (height + 7) & ~7, 0, 1);
 }
@@ -1507,6 +1562,7 @@ int lpt_set_partition(lpt_ctx* c, int tile_w, int tile_h, int rank, int n_ranks)
   if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
   if (tile_w <= 0 || tile_h <= 0 || (tile_w & 7) || (tile_h & 7)) return fail(c, LPT_ERR_INVALID, "tile size must be a positive multiple of 8");
   if (n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(c, LPT_ERR_INVALID, "bad rank / n_ranks");
+  LPT_USE_DEVICE(c);
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   return set_partition(c, c->part.W, c->part.H, tile_w, tile_h, rank, n_ranks);
 }
@@ -1530,9 +1586,12 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   int rc = ready(c);
   if (rc) return rc;
   if (!ubos || n_frames <= 0) return fail(c, LPT_ERR_INVALID, "no frames");
-  LPT_HIP(c, hipSetDevice(c->device));
-  // the previous call's events and pinned staging must be free again
+  LPT_USE_DEVICE(c);
+  // the previous call's events and pinned staging must be free again (RendererCore::drawFrame waits for
+  // its in-flight fence in the same place, src/RendererCore.cpp:376)
   LPT_HIP(c, hipStreamSynchronize(c->stream));
+  rc = check_flags(c);  // the previous call's render was cut short and nobody has asked since
+  if (rc) return rc;
   c->evUsed = 0;
   c->haveTiming = false;
   LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long), c->stream));
@@ -1591,15 +1650,21 @@ int lpt_render_frame(lpt_ctx* c, const lpt_ubo* ubo) { return lpt_render_frames(
 
 int lpt_synchronize(lpt_ctx* c) {
   if (!c) return LPT_ERR_INVALID;
+  LPT_USE_DEVICE(c);
   LPT_HIP(c, hipStreamSynchronize(c->stream));
-  return LPT_OK;
+  return check_flags(c);
 }
 
 int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   if (!c || !out) return LPT_ERR_INVALID;
   std::memset(out, 0, sizeof *out);
   if (!c->haveTiming) return fail(c, LPT_ERR_INVALID, "nothing rendered yet");
+  LPT_USE_DEVICE(c);
   LPT_HIP(c, hipStreamSynchronize(c->stream));
+  {
+    const int rc = check_flags(c);
+    if (rc) return rc;
+  }
   unsigned long long totals[kTotalsWords] = {};
   LPT_HIP(c, hipMemcpy(totals, c->dTotals, sizeof totals, hipMemcpyDeviceToHost));
 #ifdef LPT_EXTEND_STATS
@@ -1647,12 +1712,13 @@ int lpt_read_accum(lpt_ctx* c, float* dst) {
   if (!c || !dst) return LPT_ERR_INVALID;
   if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
   const Partition& P = c->part;
+  LPT_USE_DEVICE(c);
   dim3 blk(16, 16), grd((P.W + 15) / 16, (P.H + 15) / 16);
   hipLaunchKernelGGL(k_unpermute, grd, blk, 0, c->stream, P, c->dAccum, c->dImage);
   LPT_HIP(c, hipGetLastError());
   LPT_HIP(c, hipMemcpyAsync(dst, c->dImage, (size_t)P.W * P.H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
   LPT_HIP(c, hipStreamSynchronize(c->stream));
-  return LPT_OK;
+  return check_flags(c);
 }
 
 int lpt_owned_slots(lpt_ctx* c, uint64_t* n) {
@@ -1674,6 +1740,7 @@ int lpt_assemble_gathered(lpt_ctx* c, const void* gathered, int n_ranks, void* i
   if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
   if (n_ranks != c->part.nRanks) return fail(c, LPT_ERR_INVALID, "n_ranks differs from the partition");
   const Partition& P = c->part;
+  LPT_USE_DEVICE(c);
   dim3 blk(16, 16), grd((P.W + 15) / 16, (P.H + 15) / 16);
   hipLaunchKernelGGL(k_assemble, grd, blk, 0, c->stream, P, (const float4*)gathered, (float4*)image);
   LPT_HIP(c, hipGetLastError());
@@ -1684,18 +1751,33 @@ int lpt_resolve(lpt_ctx* c, float inv_sample_count, float* dst) {
   if (!c || !dst) return LPT_ERR_INVALID;
   if (!c->sized) return fail(c, LPT_ERR_INVALID, "lpt_resize has not been called");
   const Partition& P = c->part;
+  LPT_USE_DEVICE(c);
   dim3 blk(16, 16), grd((P.W + 15) / 16, (P.H + 15) / 16);
   hipLaunchKernelGGL(k_resolve, grd, blk, 0, c->stream, P, c->dAccum, inv_sample_count, c->dImage);
   LPT_HIP(c, hipGetLastError());
   LPT_HIP(c, hipMemcpyAsync(dst, c->dImage, (size_t)P.W * P.H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
   LPT_HIP(c, hipStreamSynchronize(c->stream));
+  return check_flags(c);
+}
+
+int lpt_debug_set_trace_round_limit(lpt_ctx* c, uint32_t rounds) {
+  if (!c) return LPT_ERR_INVALID;
+  c->traceRoundLimit = rounds ? rounds : (uint32_t)LPT_TRACE_ROUND_LIMIT;
   return LPT_OK;
 }
 
 int lpt_debug_math(lpt_ctx* c, int op, const float* a, const float* b, float* out, uint32_t n) {
   if (!c || !a || !out || n == 0) return LPT_ERR_INVALID;
-  LPT_HIP(c, hipSetDevice(c->device));
+  LPT_USE_DEVICE(c);
   float *da = nullptr, *db = nullptr, *dout = nullptr;
+  struct Cleanup {  // the buffers go on every path out of this function
+    float *&a, *&b, *&o;
+    ~Cleanup() {
+      (void)hipFree(a);
+      (void)hipFree(b);
+      (void)hipFree(o);
+    }
+  } cleanup{da, db, dout};
   LPT_HIP(c, hipMalloc(&da, n * sizeof(float)));
   LPT_HIP(c, hipMalloc(&dout, n * sizeof(float)));
   LPT_HIP(c, hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
@@ -1707,9 +1789,6 @@ int lpt_debug_math(lpt_ctx* c, int op, const float* a, const float* b, float* ou
   LPT_HIP(c, hipGetLastError());
   LPT_HIP(c, hipStreamSynchronize(c->stream));
   LPT_HIP(c, hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost));
-  (void)hipFree(da);
-  (void)hipFree(db);
-  (void)hipFree(dout);
   return LPT_OK;
 }
 
@@ -1717,9 +1796,20 @@ int lpt_debug_intersect(lpt_ctx* c, const float* o, const float* d, uint32_t n, 
                         uint32_t* prim) {
   if (!c || !o || !d || !t || !obj || !prim || n == 0) return LPT_ERR_INVALID;
   if (!c->sceneLoaded) return fail(c, LPT_ERR_INVALID, "no scene uploaded");
-  LPT_HIP(c, hipSetDevice(c->device));
+  LPT_USE_DEVICE(c);
   float *dO = nullptr, *dD = nullptr, *dT = nullptr;
   uint32_t *dObj = nullptr, *dPrim = nullptr;
+  struct Cleanup {  // the buffers go on every path out of this function
+    float *&o, *&d, *&t;
+    uint32_t *&obj, *&prim;
+    ~Cleanup() {
+      (void)hipFree(o);
+      (void)hipFree(d);
+      (void)hipFree(t);
+      (void)hipFree(obj);
+      (void)hipFree(prim);
+    }
+  } cleanup{dO, dD, dT, dObj, dPrim};
   LPT_HIP(c, hipMalloc(&dO, 3 * (size_t)n * sizeof(float)));
   LPT_HIP(c, hipMalloc(&dD, 3 * (size_t)n * sizeof(float)));
   LPT_HIP(c, hipMalloc(&dT, n * sizeof(float)));
@@ -1737,11 +1827,6 @@ int lpt_debug_intersect(lpt_ctx* c, const float* o, const float* d, uint32_t n, 
   LPT_HIP(c, hipMemcpy(t, dT, n * sizeof(float), hipMemcpyDeviceToHost));
   LPT_HIP(c, hipMemcpy(obj, dObj, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   LPT_HIP(c, hipMemcpy(prim, dPrim, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  (void)hipFree(dO);
-  (void)hipFree(dD);
-  (void)hipFree(dT);
-  (void)hipFree(dObj);
-  (void)hipFree(dPrim);
   return LPT_OK;
 }
 

@@ -40,7 +40,9 @@ namespace lpt {
 #endif
 // Upper bound on the rounds of one wave, far above any real batch (a wave of the largest batch,
 // 256 Mi paths, runs a few hundred thousand): an exit every wave reaches within seconds even if
-// a lane's state were corrupted.
+// a lane's state were corrupted.  A wave that runs into it raises flags[0], and the next call that
+// synchronises with the stream returns LPT_ERR_TRUNCATED.  The limit in force is a launch argument
+// (default: this constant; lpt_debug_set_trace_round_limit lowers it for tests).
 #ifndef LPT_TRACE_ROUND_LIMIT
 #define LPT_TRACE_ROUND_LIMIT (1u << 24)
 #endif
@@ -71,7 +73,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
                                                  const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
                                                  uint32_t maxBounces, int bsdfMode, float4* __restrict__ samples,
                                                  uint32_t* cursor, unsigned long long* totals,
-                                                 TraceShared<S, BLOCK>& sh, const TraceQueue& src) {
+                                                 TraceShared<S, BLOCK>& sh, const TraceQueue& src, uint32_t* flags,
+                                                 uint32_t roundLimit) {
   uint32_t* stk = &sh.stack[threadIdx.x];
   const uint32_t lane = threadIdx.x & 63u;
   // path ids of the batch (frame-major, slot-minor), or the queue's entries
@@ -114,7 +117,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
 #else
 #define LPT_STAT(k, lanes) ((void)0)
 #endif
-  for (uint32_t round = 0; round < LPT_TRACE_ROUND_LIMIT; ++round) {
+  for (uint32_t round = 0; round < roundLimit; ++round) {
 #ifdef LPT_TRACE_STATS
     {
       const long long now = clock64();
@@ -417,6 +420,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
       g5 = inObj ? 1u : 0u;
     }
   }
+
+  // Out of rounds with paths unfinished: their samples are missing, and the host must hear of it
+  // (flags[0] is host memory the host reads after synchronising with the stream).
+  if (__ballot(state != kTsDone) != 0ull && lane == 0u) flags[0] = 1u;
 
   // per-wave totals, one atomic pair per wave
   for (int off = 32; off > 0; off >>= 1) {

@@ -1,5 +1,7 @@
 #include "lsg_bvh.hpp"
 
+#include "../../include/lpt.h"
+
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -34,12 +36,15 @@ struct Split {
 };
 
 constexpr int kMaxDepth = 40;
-constexpr uint32_t kHardLeafLimit = 100;  // leaves are encoded with a 7-bit count on the device
+// Beyond kMaxDepth a node stops looking for good splits, but it still halves its list until it fits a
+// leaf the device layer accepts.
+constexpr uint32_t kHardLeafLimit = LPT_MAX_LEAF_PRIMITIVES;
 
 class Builder {
  public:
   Builder(const BuildOptions& opt, const TriangleAccessor<vec3>* tris) : opt_(opt), tris_(tris) {
     bins_ = (int)std::max<uint32_t>(2, std::min<uint32_t>(opt.bins, 64));
+    opt_.maxLeafSize = std::max<uint32_t>(1, std::min<uint32_t>(opt.maxLeafSize, kHardLeafLimit));
   }
 
   Ref<BVH<float>> run(std::vector<PrimRef>&& refs) {

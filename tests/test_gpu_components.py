@@ -267,3 +267,91 @@ def test_batch_shrinks_when_device_memory_is_short(cornell):
         assert st.paths == 32 * 8192 * 8192 and st.segments == st.paths
     finally:
         dev.close()
+
+
+def _leaf(first, last, lo=(-1, -1, -1), hi=(1, 1, 1)):
+    n = np.zeros(1, dtype=L._native.NODE_DTYPE)
+    n["minCorner"], n["maxCorner"], n["isLeaf"], n["indices"] = lo, hi, 1, (first, last)
+    return n
+
+
+def test_upload_checks_leaf_size_and_shared_mesh_trees(cornell):
+    """lpt_upload_scene refuses what the device layer's references cannot express: leaves of more than 63
+    primitives, and mesh-tree nodes shared by objects that differ in bvhOffset or verticesOffset.  Instances
+    (same bvhOffset, same verticesOffset) are accepted and render like the oracle."""
+    dev = L.Device(0)
+    try:
+        obj = cornell.objects[:1].copy()
+        obj["bvhOffset"], obj["verticesOffset"] = 0, 0
+        verts = np.zeros(3 * 70, dtype=L._native.VERTEX_DTYPE)
+        verts["position"] = np.tile(np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], F32), (70, 1))
+        verts["normal"] = (0, 0, 1)
+        top = _leaf(0, 1)
+        big = L.Scene.from_buffers(obj, top, verts, _leaf(0, 64))
+        with pytest.raises(L.LptError, match="more than 63"):
+            dev.upload_scene(big)
+        dev.upload_scene(L.Scene.from_buffers(obj, top, verts, _leaf(0, 63)))  # the limit itself is fine
+        # two objects, one mesh tree, different vertex ranges: refused
+        two = np.concatenate([obj, obj])
+        two["verticesOffset"] = (0, 3)
+        with pytest.raises(L.LptError, match="shared by objects") as e:
+            dev.upload_scene(L.Scene.from_buffers(two, _leaf(0, 2), verts, _leaf(0, 4)))
+        assert e.value.status == -2
+        # an object whose tree starts inside another object's tree: refused as well
+        inner = np.zeros(1, dtype=L._native.NODE_DTYPE)
+        inner["minCorner"], inner["maxCorner"], inner["indices"] = (-1, -1, -1), (1, 1, 1), (1, 2)
+        mesh = np.concatenate([inner, _leaf(0, 2), _leaf(2, 4)])
+        two["verticesOffset"] = (0, 0)
+        two["bvhOffset"] = (0, 1)
+        with pytest.raises(L.LptError, match="shared by objects"):
+            dev.upload_scene(L.Scene.from_buffers(two, _leaf(0, 2), verts, mesh))
+        # true instances: same tree, same vertices, different transforms
+        two["bvhOffset"] = (0, 0)
+        two["worldMatrix"][1][12] = 2.5          # second instance moved along x
+        two["worldMatrixInverse"][1][12] = -2.5
+        cam = np.eye(4, dtype=F32)
+        cam[3, :3] = (1.2, 0, 6)
+        inst = L.Scene.from_buffers(two, _leaf(0, 2, (-1, -1, -1), (3.5, 1, 1)), verts, mesh, cam.reshape(16), 0.8)
+        ubos = L.frame_ubos(inst.camera_world, inst.fov_y, 2, seed=9)
+        ref, st = O.render_frames(O.OracleScene(inst.objects, inst.object_bvh, inst.vertices, inst.mesh_bvh), ubos, 96, 64, 3)
+        assert st["hits"] > 0
+        dev.upload_scene(inst)
+        dev.resize(96, 64)
+        for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_HYBRID, L.PIPELINE_MEGAKERNEL):
+            dev.set_options(3, L.BSDF_HEITZ, pipeline, 0)
+            dev.render_frames(ubos)
+            assert dev.stats().segments == st["segments"]
+            assert np.array_equal(dev.read_accum(), ref)
+    finally:
+        dev.close()
+
+
+def test_persistent_launch_out_of_rounds_is_reported(cornell, cornell_oracle):
+    """A persistent launch that runs out of scheduling rounds leaves paths unfinished; the next call that
+    waits for the stream must say so (LPT_ERR_TRUNCATED) instead of handing out an incomplete image, and
+    the context must work again afterwards."""
+    w, h, bounces = 256, 256, 8
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, 4, seed=13)
+    dev = L.Device(0)
+    try:
+        dev.upload_scene(cornell)
+        dev.resize(w, h)
+        for pipeline in (L.PIPELINE_PERSISTENT, L.PIPELINE_HYBRID, L.PIPELINE_WAVEFRONT):
+            dev.set_options(bounces, L.BSDF_HEITZ, pipeline, 0)
+            dev.debug_set_trace_round_limit(16)
+            dev.render_frames(ubos)
+            with pytest.raises(L.LptError) as e:
+                dev.stats()
+            assert e.value.status == -6 and "round limit" in str(e.value)
+            dev.synchronize()  # the flag is reported once
+            dev.render_frames(ubos)
+            with pytest.raises(L.LptError):
+                dev.read_accum()
+            dev.debug_set_trace_round_limit(0)
+            dev.resize(w, h)
+            dev.render_frames(ubos)
+            ref, st = O.render_frames(cornell_oracle, ubos, w, h, bounces)
+            assert dev.stats().segments == st["segments"]
+            assert np.array_equal(dev.read_accum(), ref)
+    finally:
+        dev.close()

@@ -1,0 +1,160 @@
+"""The benchmark's larger configurations on the HIP path, through the C-ABI.
+
+ * C3: open 400 k-triangle scene, 1920x1080, 8 bounces — size-independent properties at full size, oracle
+   parity at a size the oracle covers.
+ * C4: Cornell box cut into tiles over 8 ranks, 8 bounces — the assembled image equals the unsharded one
+   (against the oracle at a reduced size, GPU against GPU at 3840x2160).
+ * C5: the open scene at 16 bounces with the Heitz BSDFs, whole and over 8 ranks.
+
+`outside_synth` stands in for the reference's resources/outside.gltf, whose binary buffer is absent
+upstream (same object/triangle/material shape; logipathtracer_amd/scenes.py)."""
+import numpy as np
+import pytest
+
+import logipathtracer_amd as L
+from conftest import rel_l2
+from logipathtracer_amd import scenes
+from logipathtracer_amd.partition import Partition
+from oracle import binding as O
+
+pytestmark = pytest.mark.gpu
+
+ALL_PIPELINES = (L.PIPELINE_WAVEFRONT, L.PIPELINE_MEGAKERNEL, L.PIPELINE_PERSISTENT, L.PIPELINE_HYBRID)
+
+
+@pytest.fixture(scope="module")
+def outside(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("outside") / "outside_synth.gltf")
+    n = scenes.write_outside_synth(path, 1.0)
+    assert 380_000 <= n <= 420_000
+    s = L.Scene(path)
+    return s, O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
+
+
+def _render(device, scene, ubos, w, h, bounces, pipeline, fif=0, upload=True):
+    if upload:
+        device.upload_scene(scene)
+    device.resize(w, h)
+    device.set_options(bounces, L.BSDF_HEITZ, pipeline, fif)
+    device.render_frames(ubos)
+    return device.read_accum(), device.stats()
+
+
+def _render_sharded(scene, ubos, w, h, bounces, tile, ranks, pipelines):
+    """Every rank's share rendered in turn on the one GPU, gathered as an all-gather of the ranks' compact
+    buffers would deliver them, and assembled by lpt_assemble_gathered.  Returns (image, segments)."""
+    torch = pytest.importorskip("torch")
+    bufs, seg, first = [], 0, None
+    P = Partition(w, h, tile, tile, ranks)
+    for r in range(ranks):
+        dev = L.Device(0)
+        dev.upload_scene(scene)
+        dev.resize(w, h)
+        dev.set_partition(tile, tile, r, ranks)
+        dev.set_options(bounces, L.BSDF_HEITZ, pipelines[r % len(pipelines)], 0)
+        dev.render_frames(ubos)
+        seg += dev.stats().segments
+        assert dev.owned_slots() == P.n_slots
+        n_floats = dev.owned_slots() * 4
+
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4",
+                                        "data": (dev.owned_accum_device(), False), "version": 3}
+
+        bufs.append(torch.as_tensor(_Arr(), device="cuda:0").clone())
+        if first is None:
+            first = dev
+        else:
+            dev.close()
+    gathered = torch.cat(bufs)
+    image = torch.empty(h * w * 4, dtype=torch.float32, device="cuda:0")
+    first.assemble_gathered(gathered.data_ptr(), ranks, image.data_ptr())
+    first.synchronize()
+    out = image.cpu().numpy().reshape(h, w, 4)
+    first.close()
+    return out, seg
+
+
+def test_c5_outside_16_bounces_matches_oracle(device, outside):
+    s, osc = outside
+    w, h, bounces = 320, 180, 16
+    ubos = L.frame_ubos(s.camera_world, s.fov_y, 2, seed=0x5EED)
+    ref, st = O.render_frames(osc, ubos, w, h, bounces)
+    assert st["stackOverflow"] == 0
+    assert st["segments"] > 3 * st["paths"]  # the scene is closed by its sky shell: paths are long
+    device.upload_scene(s)
+    for pipeline in ALL_PIPELINES:
+        img, gst = _render(device, s, ubos, w, h, bounces, pipeline, upload=False)
+        assert gst.paths == st["paths"] and gst.segments == st["segments"], pipeline
+        assert rel_l2(img, ref) <= 1e-4
+        assert np.array_equal(img, ref), pipeline
+
+
+def test_c5_outside_16_bounces_over_8_ranks(outside):
+    s, osc = outside
+    w, h, bounces, tile, ranks = 320, 180, 16, 64, 8  # 15 tiles over 8 ranks: the last rank holds one, edge tiles stick out
+    ubos = L.frame_ubos(s.camera_world, s.fov_y, 2, seed=0x5EED)
+    ref, st = O.render_frames(osc, ubos, w, h, bounces)
+    img, seg = _render_sharded(s, ubos, w, h, bounces, tile, ranks,
+                               (L.PIPELINE_WAVEFRONT, L.PIPELINE_HYBRID, L.PIPELINE_PERSISTENT))
+    assert seg == st["segments"]
+    assert np.array_equal(img, ref)
+
+
+def test_c4_cornell_over_8_ranks_matches_oracle(cornell, cornell_oracle):
+    w, h, bounces, tile, ranks = 384, 216, 8, 64, 8  # the 4K image at a tenth of its side
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, 3, seed=0x5EED)
+    ref, st = O.render_frames(cornell_oracle, ubos, w, h, bounces)
+    img, seg = _render_sharded(cornell, ubos, w, h, bounces, tile, ranks,
+                               (L.PIPELINE_HYBRID, L.PIPELINE_WAVEFRONT, L.PIPELINE_PERSISTENT))
+    assert seg == st["segments"]
+    assert np.array_equal(img, ref)
+
+
+def test_c4_full_size_8_ranks_equal_one_gpu(device, cornell):
+    """3840x2160, 8 bounces: the image assembled from 8 ranks' tiles is the single-context image, bit for bit."""
+    w, h, bounces, spp = 3840, 2160, 8, 2
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, spp, seed=0x5EED)
+    whole, st = _render(device, cornell, ubos, w, h, bounces, L.PIPELINE_AUTO)
+    assert st.paths == w * h * spp and np.all(whole[..., 3] == spp)
+    img, seg = _render_sharded(cornell, ubos, w, h, bounces, 64, 8, (L.PIPELINE_AUTO,))
+    assert seg == st.segments
+    assert np.array_equal(img, whole)
+
+
+def test_c3_outside_full_size_properties(device, outside):
+    """1920x1080, 8 bounces, 8 frames of the open scene: the four organisations agree bit for bit, alpha
+    counts the samples, paths = W*H*spp, every path traces between 1 and 8 segments."""
+    s, _ = outside
+    w, h, spp, bounces = 1920, 1080, 8, 8
+    ubos = L.frame_ubos(s.camera_world, s.fov_y, spp, seed=0x5EED)
+    device.upload_scene(s)
+    images, segments = [], []
+    for pipeline, fif in ((L.PIPELINE_WAVEFRONT, 0), (L.PIPELINE_PERSISTENT, 0), (L.PIPELINE_HYBRID, 0),
+                          (L.PIPELINE_HYBRID, 3), (L.PIPELINE_MEGAKERNEL, 0)):
+        img, st = _render(device, s, ubos, w, h, bounces, pipeline, fif=fif, upload=False)
+        assert st.paths == w * h * spp
+        assert st.paths <= st.segments <= bounces * st.paths
+        assert np.all(img[..., 3] == spp)
+        assert np.isfinite(img[..., :3]).all() and img[..., :3].min() >= 0.0
+        images.append(img)
+        segments.append(st.segments)
+    assert len(set(segments)) == 1
+    for other in images[1:]:
+        assert np.array_equal(images[0], other)
+
+
+def test_c5_outside_4k_16_bounces_properties(device, outside):
+    """3840x2160, 16 bounces on the open scene (one frame): wavefront, hybrid and persistent organisations agree
+    bit for bit and every path is accounted for."""
+    s, _ = outside
+    w, h, bounces = 3840, 2160, 16
+    ubos = L.frame_ubos(s.camera_world, s.fov_y, 1, seed=0x5EED)
+    device.upload_scene(s)
+    results = [_render(device, s, ubos, w, h, bounces, p, upload=False)
+               for p in (L.PIPELINE_WAVEFRONT, L.PIPELINE_HYBRID, L.PIPELINE_PERSISTENT)]
+    for img, st in results:
+        assert st.paths == w * h and st.paths <= st.segments <= bounces * st.paths
+        assert np.all(img[..., 3] == 1.0) and np.isfinite(img).all()
+    assert results[0][1].segments == results[1][1].segments == results[2][1].segments
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][0], results[2][0])

@@ -170,3 +170,26 @@ def test_partition_maps_are_bijective(w, h, tw, th, ranks):
             cover[y0:y0 + th_, x0:x0 + tw_] += 1
             assert np.all(owner[y0:y0 + th_, x0:x0 + tw_] == r)
     assert np.all(cover == 1)
+
+
+def test_builder_never_emits_leaves_beyond_the_device_limit(tmp_path, monkeypatch):
+    """150 triangles with one centroid and a requested leaf size of 200: no split plane separates them, so
+    the builder halves the list — and it must go on halving until every leaf fits the 6-bit count of the
+    device layer's traversal references (63), whatever leaf size was asked for."""
+    from logipathtracer_amd import scenes
+    g = scenes._GltfBuilder()
+    m = g.material("M", (0.7, 0.6, 0.5, 1), 0.3, 0.4)
+    tri = np.tile(np.array([[-1, -1, 0], [1, -1, 0], [0, 2, 0]], np.float32), (150, 1))
+    nrm = np.tile([0, 0, 1], (450, 1)).astype(np.float32)
+    g.node("Pile", mesh=g.mesh("Pile", [(tri, nrm, np.arange(450, dtype=np.uint32), m)]))
+    g.node("Camera", camera=g.camera(0.8), translation=(0, 0, 4))
+    path = str(tmp_path / "pile.gltf")
+    g.write(path)
+    monkeypatch.setenv("LPT_BVH_CHILD_ORDER", "0")
+    monkeypatch.setenv("LPT_BVH_LEAF", "200")
+    for builder in (L.BUILDER_SPLIT_BVH, L.BUILDER_BINNED_SAH):
+        s = L.Scene(path, builder=builder)
+        leaves = s.mesh_bvh[s.mesh_bvh["isLeaf"] != 0]
+        counts = leaves["indices"][:, 1].astype(np.int64) - leaves["indices"][:, 0]
+        assert counts.sum() == 150 and counts.max() <= 63 and len(leaves) >= 3
+        _check_tree(s.mesh_bvh, 0, 150)
