@@ -211,6 +211,17 @@ int lpt_set_options(lpt_ctx* ctx, int max_bounces, int bsdf_mode, int pipeline, 
 int lpt_render_frames(lpt_ctx* ctx, const lpt_ubo* ubos, int n_frames);
 /* One frame; the call RendererPT::drawFrame lands on. */
 int lpt_render_frame(lpt_ctx* ctx, const lpt_ubo* ubo);
+/* One frame without any allocation.  No counterpart in the reference: it is for callers that cannot
+ * allocate device memory at this point — code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  Same result as lpt_render_frame (bit for bit), rendered by the persistent
+ * organisation whatever lpt_set_options chose; its working memory (ray cursors, the uniform block, one
+ * RGBA32F sample per owned pixel slot) is a static device array of 36 MiB that every GPU the library runs
+ * on holds until the process ends.  Limits: a context that owns more than 2 359 296 pixel slots (above
+ * 1920x1080) gets LPT_ERR_UNSUPPORTED; lpt_upload_scene and lpt_resize (which do allocate) must have been
+ * called before.  All contexts on one GPU share the array: calls on different contexts or streams of one
+ * GPU must not overlap (calls on one context are ordered by its stream).  Queues its work and returns;
+ * lpt_synchronize / lpt_get_stats / lpt_read_accum wait for it.  lpt_stats.extend_ms is 0 for it. */
+int lpt_render_frame_static(lpt_ctx* ctx, const lpt_ubo* ubo);
 /* Blocks until all submitted work of the context has finished. */
 int lpt_synchronize(lpt_ctx* ctx);
 int lpt_get_stats(lpt_ctx* ctx, lpt_stats* out);

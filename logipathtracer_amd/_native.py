@@ -69,6 +69,7 @@ LPT_SYMBOLS = [
     "lpt_set_partition", "lpt_set_options", "lpt_render_frames", "lpt_render_frame", "lpt_synchronize",
     "lpt_get_stats", "lpt_read_accum", "lpt_owned_slots", "lpt_owned_accum_device", "lpt_assemble_gathered",
     "lpt_resolve", "lpt_build_mesh_bvh", "lpt_debug_math", "lpt_debug_intersect", "lpt_debug_set_trace_round_limit",
+    "lpt_render_frame_static",
 ]
 
 _vp, _u32, _i = C.c_void_p, C.c_uint32, C.c_int
@@ -92,6 +93,7 @@ _sig(hip, "lpt_set_partition", _i, _vp, _i, _i, _i, _i)
 _sig(hip, "lpt_set_options", _i, _vp, _i, _i, _i, _i)
 _sig(hip, "lpt_render_frames", _i, _vp, _vp, _i)
 _sig(hip, "lpt_render_frame", _i, _vp, _vp)
+_sig(hip, "lpt_render_frame_static", _i, _vp, _vp)
 _sig(hip, "lpt_synchronize", _i, _vp)
 _sig(hip, "lpt_debug_set_trace_round_limit", _i, _vp, _u32)
 _sig(hip, "lpt_get_stats", _i, _vp, C.POINTER(Stats))

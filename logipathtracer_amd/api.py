@@ -162,6 +162,13 @@ class Device:
         ubos = np.ascontiguousarray(ubos, dtype=N.UBO_DTYPE)
         self._check(N.hip.lpt_render_frames(self._ctx, _ptr(ubos), len(ubos)))
 
+    def render_frame_static(self, ubo):
+        """One frame through the entry point that allocates nothing (see include/lpt.h)."""
+        ubo = np.ascontiguousarray(ubo, dtype=N.UBO_DTYPE).reshape(-1)
+        if len(ubo) != 1:
+            raise ValueError("exactly one uniform block")
+        self._check(N.hip.lpt_render_frame_static(self._ctx, _ptr(ubo)))
+
     def synchronize(self):
         self._check(N.hip.lpt_synchronize(self._ctx))
 

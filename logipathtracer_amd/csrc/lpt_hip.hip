@@ -613,6 +613,21 @@ __global__ __launch_bounds__(kBlock) void k_debug_intersect(DScene sc, const flo
   prim[i] = h.prim;
 }
 
+// ---- scratch of the entry point that allocates nothing (lpt_render_frame_static) ---------------
+// One array per GPU, held from the moment the library is loaded on it until the process ends.  Layout:
+// [0, 1 KiB) the ray cursors of the persistent launch and the frame's uniform block, then one RGBA32F
+// sample per owned pixel slot.  The name below is a host-side stand-in: host code uses the device address
+// lpt_create obtains with hipGetSymbolAddress (lpt_ctx::dStatic), never the name.
+constexpr uint32_t kStaticMaxSlots = 2304u * 1024u;  // 2 359 296 pixel slots: up to 1920x1080 (36 MiB of samples)
+constexpr size_t kStaticHeaderBytes = 1024;
+constexpr size_t kStaticUboOffset = 256;
+constexpr size_t kStaticBytes = kStaticHeaderBytes + (size_t)kStaticMaxSlots * sizeof(float4);
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+__global__ void k_store_ubo(lpt_ubo value, lpt_ubo* dst) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dst = value;
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -676,6 +691,7 @@ struct lpt_ctx {
   volatile uint32_t* hFlags = nullptr;
   uint32_t* dFlags = nullptr;
   uint32_t traceRoundLimit = LPT_TRACE_ROUND_LIMIT;
+  unsigned char* dStatic = nullptr;  // this GPU's copy of `scratch` (device address)
 
   // timing of the last lpt_render_frames call
   hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -986,8 +1002,10 @@ void launch_shade(lpt_ctx* c, const Queue& in, const Queue& out, uint32_t b, uin
                      c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
 }
 
+// `ubos` / `samples`: null = the context's pool (c->dUbos, c->dSamples)
 template <bool QUEUED>
-void dispatch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src);
+void dispatch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src, const lpt_ubo* ubos = nullptr,
+                    float4* samples = nullptr);
 
 int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   int rc = ensure_pool(c, frames);
@@ -1041,7 +1059,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
 
 // QUEUED: the paths come from `src` (at most frames * slots entries), `cursor` = kCursorRegions zeroed words.
 template <int S, bool QUEUED>
-void launch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src) {
+void launch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src, const lpt_ubo* ubos, float4* samples) {
   // persistent grid: exactly as many workgroups as are resident at once (registers and LDS decide)
   static const int resident = [] {
     int n = 0;
@@ -1054,19 +1072,19 @@ void launch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& sr
   const size_t paths = (size_t)frames * c->part.nSlots;
   const size_t need = (paths + kBlock - 1) / kBlock;
   const int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
-  hipLaunchKernelGGL((k_trace<S, QUEUED>), dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), c->part, c->dUbos,
-                     (uint32_t)frames, (uint32_t)c->maxBounces, c->bsdfMode, c->dSamples, cursor, c->dTotals, src, c->dFlags,
-                     c->traceRoundLimit);
+  hipLaunchKernelGGL((k_trace<S, QUEUED>), dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), c->part,
+                     ubos ? ubos : c->dUbos, (uint32_t)frames, (uint32_t)c->maxBounces, c->bsdfMode,
+                     samples ? samples : c->dSamples, cursor, c->dTotals, src, c->dFlags, c->traceRoundLimit);
 }
 
 template <bool QUEUED>
-void dispatch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src) {
-  if (c->stackNeed <= 16) launch_trace<16, QUEUED>(c, frames, cursor, src);
-  else if (c->stackNeed <= 20) launch_trace<20, QUEUED>(c, frames, cursor, src);
-  else if (c->stackNeed <= 24) launch_trace<24, QUEUED>(c, frames, cursor, src);
-  else if (c->stackNeed <= 32) launch_trace<32, QUEUED>(c, frames, cursor, src);
-  else if (c->stackNeed <= 48) launch_trace<48, QUEUED>(c, frames, cursor, src);
-  else launch_trace<64, QUEUED>(c, frames, cursor, src);
+void dispatch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src, const lpt_ubo* ubos, float4* samples) {
+  if (c->stackNeed <= 16) launch_trace<16, QUEUED>(c, frames, cursor, src, ubos, samples);
+  else if (c->stackNeed <= 20) launch_trace<20, QUEUED>(c, frames, cursor, src, ubos, samples);
+  else if (c->stackNeed <= 24) launch_trace<24, QUEUED>(c, frames, cursor, src, ubos, samples);
+  else if (c->stackNeed <= 32) launch_trace<32, QUEUED>(c, frames, cursor, src, ubos, samples);
+  else if (c->stackNeed <= 48) launch_trace<48, QUEUED>(c, frames, cursor, src, ubos, samples);
+  else launch_trace<64, QUEUED>(c, frames, cursor, src, ubos, samples);
 }
 
 // A batch of frames as one persistent launch plus the frame-ordered accumulation.
@@ -1241,6 +1259,9 @@ int lpt_create(int device, lpt_ctx** out) {
   if ((e = hipEventCreate(&c->evStop)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&c->dTotals, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  // this GPU's copy of the static scratch array (the device is current here)
+  if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&c->dStatic), HIP_SYMBOL(scratch))) != hipSuccess)
+    return bail("hipGetSymbolAddress(scratch)", e);
   void* flags = nullptr;
   if ((e = hipHostMalloc(&flags, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
     return bail("hipHostMalloc", e);
@@ -1647,6 +1668,39 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
 }
 
 int lpt_render_frame(lpt_ctx* c, const lpt_ubo* ubo) { return lpt_render_frames(c, ubo, 1); }
+
+int lpt_render_frame_static(lpt_ctx* c, const lpt_ubo* ubo) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!ubo) return fail(c, LPT_ERR_INVALID, "no frame");
+  if (c->part.nSlots > kStaticMaxSlots)
+    return fail(c, LPT_ERR_UNSUPPORTED,
+                "lpt_render_frame_static: the context owns " + std::to_string(c->part.nSlots) + " pixel slots, the static "
+                "scratch holds " + std::to_string(kStaticMaxSlots) + " (1920x1080); use lpt_render_frame");
+  if (!c->dStatic) return fail(c, LPT_ERR_HIP, "static scratch address unknown");
+  LPT_USE_DEVICE(c);
+  // everything below is stream-ordered work on memory that exists already: the static array (cursors,
+  // uniform block, samples), the context's counters and the accumulation image
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(c->dStatic);
+  lpt_ubo* dUbo = reinterpret_cast<lpt_ubo*>(c->dStatic + kStaticUboOffset);
+  float4* samples = reinterpret_cast<float4*>(c->dStatic + kStaticHeaderBytes);
+  c->evUsed = 0;
+  c->haveTiming = false;
+  c->activePipeline = LPT_PIPELINE_PERSISTENT;
+  LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long), c->stream));
+  LPT_HIP(c, hipMemsetAsync(cursor, 0, kCursorRegions * sizeof(uint32_t), c->stream));  // the last call's cursors
+  LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
+  hipLaunchKernelGGL(k_store_ubo, dim3(1), dim3(64), 0, c->stream, *ubo, dUbo);
+  if (c->nValid)
+    dispatch_trace<false>(c, 1, cursor, TraceQueue{nullptr, nullptr, nullptr, nullptr, 0u, 1u}, dUbo, samples);
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, dUbo, 1u,
+                     samples, c->dAccum);
+  LPT_HIP(c, hipGetLastError());
+  LPT_HIP(c, hipEventRecord(c->evStop, c->stream));
+  c->lastFrames = 1;
+  c->haveTiming = true;
+  return LPT_OK;
+}
 
 int lpt_synchronize(lpt_ctx* c) {
   if (!c) return LPT_ERR_INVALID;
