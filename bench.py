@@ -15,6 +15,8 @@ the timed region; the single gather of the HDR tile buffers happens after it and
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,13 +26,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+# Vector L1 (the path every per-lane gather of the search takes): 64 B per clock and CU.
+L1_BYTES_PER_CLK_PER_CU = 64.0
+PEAK_CLOCK_GHZ = 2.4  # MI355X peak engine clock (what hipDeviceProp_t::clockRate reports on this part)
 
 
-class _DeviceArray:
-    """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it."""
-
-    def __init__(self, ptr, n_floats):
-        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False), "version": 3}
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: starts N ranks of this script under
+    torch.distributed.run (one per GPU) as a child process, relays their output and returns the exit
+    status.  Runs before anything in this process touches a GPU."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def parse_args():
@@ -90,16 +102,128 @@ def range_means(upto_hi, upto_lo):
     pl = max(upto_lo["paths"], 1) if upto_lo else 1
     lo = (lambda k: upto_lo[k] / pl) if upto_lo else (lambda k: 0.0)
     seg = upto_hi["segments"] / ph - lo("segments")  # segments of the range per camera path
-    out = {k: (upto_hi[k] / ph - lo(k)) / max(seg, 1e-9) for k in ("boxTests", "rootVisits", "triTests", "hits")}
+    out = {k: (upto_hi[k] / ph - lo(k)) / max(seg, 1e-9) for k in ("boxTests", "rootVisits", "triTests", "hits", "objectsEntered")}
     out["segments_per_path"] = seg
+    return out
+
+
+def roofline(args, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext_launches, props):
+    """Roofline block of the dominant kernel: k_extend (wavefront organisation) or k_trace.
+
+    What bounds these kernels is the vector L1: every search step is a per-lane gather of one small record
+    (64-byte node, 48-byte triangle, 64-byte object record) in 16-byte loads at unrelated addresses, and the
+    scene is cache-resident, so hardly any of it reaches HBM.  The block therefore prices the kernel against
+    the L1's nominal rate (64 B per clock and CU):
+      achieved = 16 B x the per-lane loads the kernel issues per traced segment x segments / kernel time,
+      loads per segment = 4 per inner node visited + 3 per triangle tested + 4 per object entered
+                          + the ray/queue/surface records of the kernel (below),
+    with the per-segment means taken from the CPU oracle's counters over the bounces the kernel traces and
+    the kernel time measured live with HIP events.  Beside it: the measured ceiling of such gathers on this
+    chip (profiles/r02_gather_peak.json, tools/gather_peak.hip), the algorithmic bytes in interchange terms
+    (48 B per node fetched + 36 B per triangle + state), and HBM traffic from the committed PMC passes."""
+    kernel = {0: "k_extend", 2: "k_trace", 4: "k_trace"}.get(used_pipeline, "k_megakernel")
+    packets = used_pipeline in (0, 4) and os.environ.get("LPT_PRIMARY_PACKETS", "1") != "0"
+    # the bounces whose segments the timed kernel traces: [lo, hi)
+    lo = 1 if packets else 0
+    hi = args.bounces
+    if used_pipeline == 0:  # the wavefront organisation hands the late bounces to one persistent launch
+        tail = int(os.environ.get("LPT_WAVEFRONT_TAIL", "4"))
+        if 1 <= tail < args.bounces:
+            hi = tail
+    upto_hi = counters if hi == args.bounces else traversal_counters(scene, ubos, args.width, args.height, hi)
+    upto_lo = traversal_counters(scene, ubos, args.width, args.height, lo) if lo > 0 else None
+    rm = range_means(upto_hi, upto_lo)
+    n_inner = rm["boxTests"] / 2.0  # an inner node's visit tests both of its children
+    n_node = rm["boxTests"] + rm["rootVisits"]
+    n_tri, p_hit, n_obj = rm["triTests"], rm["hits"], rm["objectsEntered"]
+    kernel_seg = float(kernel_seg)
+    # paths that enter the kernel, per camera path: every camera path at bounce 0, else the first hits that went on
+    entering = 1.0 if lo == 0 else upto_lo["hits"] / max(upto_lo["paths"], 1)
+    paths_per_seg = entering / max(rm["segments_per_path"], 1e-9)
+    search_loads = 4.0 * n_inner + 3.0 * n_tri + 4.0 * n_obj
+    if kernel == "k_extend":
+        other_loads = 2.0                 # the queued ray: origin and direction
+        state_bytes = 24.0 + 12.0
+        state_note = "36 B ray/hit"
+        loads_note = "2 for the queued ray"
+    else:
+        # per hit the surface's records: 8 loads of the object's shading record, 6 of the triangle's vertices
+        # (positions and normals); per path taken off the queue 3 loads (hybrid organisation)
+        per_path_loads = 3.0 if used_pipeline == 4 else 0.0
+        other_loads = p_hit * 14.0 + per_path_loads * paths_per_seg
+        per_path = 16.0 + (48.0 if used_pipeline == 4 else 0.0)
+        state_bytes = p_hit * (208.0 + 144.0) + per_path * paths_per_seg
+        state_note = f"352 B object+vertices per hit + {per_path:.0f} B per path"
+        loads_note = "14 per hit for the surface's records" + (" + 3 per queued path" if per_path_loads else "")
+    loads_per_seg = search_loads + other_loads
+    secs = ext_ms * 1e-3
+    achieved = 16.0 * loads_per_seg * kernel_seg / secs / 1e9
+    clock_ghz = PEAK_CLOCK_GHZ
+    cus = props.multi_processor_count
+    peak = cus * L1_BYTES_PER_CLK_PER_CU * clock_ghz  # GB/s
+    bytes_per_seg = 48.0 * n_node + 36.0 * n_tri + state_bytes
+    out = {
+        "kernel": kernel, "bound": "l1", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+        "traffic": None,
+        "note": f"achieved = 16 B x per-lane loads ({loads_per_seg:.1f} per segment: 4 per inner node, 3 per triangle, 4 per "
+                f"object entered, {loads_note}) x the segments {kernel} traced (bounces {lo} to {hi - 1}) / its time "
+                f"(HIP events); peak = {cus} CUs x 64 B/clk x {clock_ghz:.2f} GHz, the vector L1's nominal rate. Random "
+                "16-byte-granular gathers reach far less than that (gather_ceiling); HBM is not the bound: the scene is "
+                "cache-resident (hbm_from_profile)",
+        "loads_per_segment": loads_per_seg, "inner_nodes_per_segment": n_inner, "tris_per_segment": n_tri,
+        "objects_entered_per_segment": n_obj, "hits_per_segment": p_hit,
+        "avg_launch_ms": ext_ms / max(ext_launches, 1), "launches": ext_launches,
+        "segments_per_launch": kernel_seg / max(ext_launches, 1),
+        # algorithmic bytes in interchange terms (48 B per node fetched incl. both tested children, 36 B per triangle)
+        "algorithmic_bytes_per_segment": bytes_per_seg,
+        "algorithmic_gbs": bytes_per_seg * kernel_seg / secs / 1e9,
+        "algorithmic_note": f"48 B/node fetched + 36 B/triangle + {state_note}; exceeds the HBM peak because the scene is "
+                            "served from L1/L2",
+    }
+    gpath = os.path.join(ROOT, "profiles", "r02_gather_peak.json")
+    if os.path.exists(gpath):
+        try:
+            g = json.load(open(gpath))["ceilings_gbs"]
+            out["gather_ceiling"] = {
+                "l1_resident_gbs": g["records_64B_l1_resident_16KiB_table"],
+                "l2_resident_gbs": g["records_64B_l2_resident_2MiB_table"],
+                "frac_of_l1_resident": achieved / g["records_64B_l1_resident_16KiB_table"],
+                "source": "profiles/r02_gather_peak.json (random 64-byte records, every lane its own; lanes of the search "
+                          "that meet at one node share a line, so the kernel may exceed the random-address ceiling)",
+            }
+        except Exception:
+            pass
+    # HBM traffic and unit-busy fractions of this workload from the committed rocprofv3 PMC passes (not measured in this run)
+    tpath = os.path.join(ROOT, "profiles", {"k_extend": "extend_traffic.json", "k_trace": "trace_traffic.json"}.get(kernel, "none"))
+    default_workload = (os.path.basename(args.scene) == "cornell_box.gltf" and args.bounces == 8
+                        and (args.width, args.height) == (1920, 1080))
+    if os.path.exists(tpath) and default_workload:
+        try:
+            t = json.load(open(tpath))
+            if t.get("pipeline", used_pipeline) == used_pipeline:
+                per_seg = t["hbm_bytes_per_launch"] / t["segments_per_launch"]
+                gbs = per_seg * kernel_seg / secs / 1e9
+                out["hbm_from_profile"] = {
+                    "bytes_per_segment": per_seg, "bytes_per_launch": per_seg * kernel_seg / max(ext_launches, 1),
+                    "gbs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "peak_gbs": HBM_PEAK_GBS,
+                    "unit_busy": t.get("units"), "source": "profiles/" + os.path.basename(tpath),
+                    "rule": t.get("rule"),
+                }
+        except Exception:
+            pass
     return out
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"--gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        return 2
     import torch
     import torch.distributed as dist
     # LPT_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then
@@ -114,10 +238,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=cuda_dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    elif args.gpus != 1:
-        print(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks", file=sys.stderr)
-        return 2
     import logipathtracer_amd as L
+    from logipathtracer_amd.gather import gather_image
     if args.scene == "outside_synth":
         # stand-in for the reference's outside.gltf (its binary buffer is not in the snapshot)
         from logipathtracer_amd import scenes as _scenes
@@ -174,28 +296,15 @@ def main():
     # ---- after the timed region: gather the HDR tile buffers once (RCCL over xGMI) ----
     gather_ms = None
     if world > 1:
-        n_floats = dev.owned_slots() * 4
-        mine = torch.as_tensor(_DeviceArray(dev.owned_accum_device(), n_floats), device=cuda_dev)
-        gathered = torch.empty(world * n_floats, dtype=torch.float32, device=cuda_dev)
-        torch.cuda.synchronize()
-        dist.barrier()
-        g0 = time.perf_counter()
-        if backend == "nccl":
-            dist.all_gather_into_tensor(gathered, mine)
-        else:
-            host = torch.empty(world * n_floats, dtype=torch.float32)
-            dist.all_gather_into_tensor(host, mine.cpu())
-            gathered.copy_(host)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        image = torch.empty(args.height * args.width * 4, dtype=torch.float32, device=cuda_dev)
-        dev.assemble_gathered(gathered.data_ptr(), world, image.data_ptr())
-        dev.synchronize()
-        if rank == 0 and os.environ.get("LPT_BENCH_CHECK_IMAGE"):
-            # rehearsal aid: every pixel must have received all samples
-            alpha = image.view(args.height, args.width, 4)[..., 3]
+        image, gather_ms = gather_image(dev, world, args.width, args.height, cuda_dev, backend)
+        if rank == 0:
+            # every pixel must have received every sample of the run, from whichever rank owns it
+            alpha = image[..., 3]
             expect = float(spp_step * n_steps_total)
-            assert bool((alpha == expect).all()), (float(alpha.min()), float(alpha.max()), expect)
+            if not bool((alpha == expect).all()):
+                print(f"gathered image is incomplete: alpha in [{float(alpha.min())}, {float(alpha.max())}], "
+                      f"expected {expect}", file=sys.stderr)
+                return 3
 
     if world > 1:
         t = torch.tensor([elapsed, float(seg), float(paths), ext_ms, float(ext_launches)], dtype=torch.float64,
@@ -251,77 +360,8 @@ def main():
         else:
             counters = traversal_counters(scene, ubos, args.width, args.height, args.bounces)
         result["cpu_baseline"] = cpu
-        # Roofline of the dominant kernel.  Algorithmic bytes per traced segment, in interchange terms:
-        # 48 B per node fetched + 36 B per triangle tested, plus
-        #   k_extend (wavefront):  24 B ray in + 12 B hit out;
-        #   k_trace:  per hit the object record and three vertices (208 + 144 B), per path the 16 B radiance
-        #             sample and, when the paths come from the queue (hybrid), the 48 B queue entry.
-        # With camera rays traced by the packet kernel the dominant kernel sees the later segments only:
-        # its means are those of the full run minus those of a run cut after the first segment.
-        if counters and ext_ms > 0:
-            kernel = {0: "k_extend", 2: "k_trace", 4: "k_trace"}.get(used_pipeline, "k_megakernel")
-            packets = used_pipeline in (0, 4) and os.environ.get("LPT_PRIMARY_PACKETS", "1") != "0"
-            # the bounces whose segments the timed kernel traces: [lo, hi)
-            lo = 1 if packets else 0
-            hi = args.bounces
-            if used_pipeline == 0:  # the wavefront organisation hands the late bounces to one persistent launch
-                tail = int(os.environ.get("LPT_WAVEFRONT_TAIL", "4"))
-                if 1 <= tail < args.bounces:
-                    hi = tail
-            upto_hi = counters if hi == args.bounces else traversal_counters(scene, ubos, args.width, args.height, hi)
-            upto_lo = traversal_counters(scene, ubos, args.width, args.height, lo) if lo > 0 else None
-            rm = range_means(upto_hi, upto_lo)
-            n_node = rm["boxTests"] + rm["rootVisits"]
-            n_tri, p_hit = rm["triTests"], rm["hits"]
-            kernel_seg = float(kernel_seg_total)
-            # paths that enter the kernel, per camera path: every camera path at bounce 0, else the first hits
-            # that went on (only lo = 1 occurs with per-path bytes: the hybrid organisation)
-            entering = 1.0 if lo == 0 else upto_lo["hits"] / max(upto_lo["paths"], 1)
-            paths_per_seg = entering / max(rm["segments_per_path"], 1e-9)
-            if kernel == "k_extend":
-                state_bytes = 24.0 + 12.0
-                state_note = "36 B ray/hit"
-            else:
-                per_path = 16.0 + (48.0 if used_pipeline == 4 else 0.0)
-                state_bytes = p_hit * (208.0 + 144.0) + per_path * paths_per_seg
-                state_note = f"352 B object+vertices per hit + {per_path:.0f} B per path"
-            bytes_per_seg = 48.0 * n_node + 36.0 * n_tri + state_bytes
-            achieved = bytes_per_seg * kernel_seg / (ext_ms * 1e-3) / 1e9
-            result["kernel_segments"] = kernel_seg
-            # HBM bytes per launch: PMC measurement of this workload (profiles/*_traffic.json holds bytes
-            # and segments per launch of the profiled run), scaled to this run's segments per launch
-            traffic = None
-            units = None
-            tpath = os.path.join(ROOT, "profiles", {"k_extend": "extend_traffic.json", "k_trace": "trace_traffic.json"}
-                                 .get(kernel, "none"))
-            default_workload = (os.path.basename(args.scene) == "cornell_box.gltf" and args.bounces == 8
-                                and (args.width, args.height) == (1920, 1080))
-            if os.path.exists(tpath) and default_workload:
-                try:
-                    t = json.load(open(tpath))
-                    if t.get("pipeline", used_pipeline) == used_pipeline:
-                        units = t.get("units")
-                        traffic = t["hbm_bytes_per_launch"] / t["segments_per_launch"] * kernel_seg / max(ext_launches, 1)
-                except Exception:
-                    traffic = None
-            avg_s = ext_ms * 1e-3 / max(ext_launches, 1)
-            result["roofline"] = {
-                "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "hbm_measured_gbs": (traffic / avg_s / 1e9) if traffic else None,
-                "note": f"achieved = algorithmic bytes (48 B/node fetched + 36 B/triangle + {state_note}) x the segments "
-                        f"{kernel} traced (bounces {lo} to {hi - 1})"
-                        + f" / {kernel} time; the scene is cache-resident, so measured HBM traffic is far lower and "
-                        "the kernel is bound by the L1 gather path and vector issue, not by HBM",
-                "bytes_per_segment": bytes_per_seg, "nodes_per_segment": n_node, "tris_per_segment": n_tri,
-                "hits_per_segment": p_hit,
-                # busy fractions of the units that do bound the kernel, from the committed PMC passes of this workload
-                "measured_unit_busy": units,
-                "avg_launch_ms": ext_ms / max(ext_launches, 1), "launches": ext_launches,
-                "segments_per_launch": kernel_seg / max(ext_launches, 1),
-            }
-        else:
-            result["roofline"] = None
+        result["roofline"] = roofline(args, scene, ubos, counters, used_pipeline, kernel_seg_total, ext_ms, ext_launches,
+                                      torch.cuda.get_device_properties(device_index)) if counters and ext_ms > 0 else None
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
