@@ -118,6 +118,9 @@ _sig(host, "lpth_scene_texture", _vp, _vp, _u32, C.POINTER(_u32 * 5))
 _sig(host, "lpth_renderer_create", _vp, _i, _i, C.c_float, _i)
 _sig(host, "lpth_renderer_destroy", None, _vp)
 _sig(host, "lpth_renderer_load_gltf", _i, _vp, C.c_char_p, _i)
+_sig(host, "lpth_renderer_load_gltf_async", _i, _vp, C.c_char_p, _i)
+_sig(host, "lpth_renderer_load_wait", _i, _vp)
+_sig(host, "lpth_renderer_scene_loaded", _i, _vp)
 _sig(host, "lpth_renderer_configure", _i, _vp, _u32, _i, _i, _i, _i)
 _sig(host, "lpth_renderer_draw_frame", _i, _vp)
 _sig(host, "lpth_renderer_draw_frames", _i, _vp, _u32)

@@ -259,6 +259,17 @@ class Renderer:
     def load_scene(self, gltf_path, builder=BUILDER_SPLIT_BVH):
         self._check(N.host.lpth_renderer_load_gltf(self._h, str(gltf_path).encode(), builder))
 
+    def load_scene_async(self, gltf_path, builder=BUILDER_SPLIT_BVH):
+        """Starts RendererPT::loadScene on a second host thread (as src/Main.cpp:45 does) and returns."""
+        self._check(N.host.lpth_renderer_load_gltf_async(self._h, str(gltf_path).encode(), builder))
+
+    def wait_for_scene(self):
+        self._check(N.host.lpth_renderer_load_wait(self._h))
+
+    @property
+    def scene_loaded(self):
+        return bool(N.host.lpth_renderer_scene_loaded(self._h))
+
     def configure(self, seed=0x5EED, max_bounces=10, bsdf_mode=BSDF_HEITZ, pipeline=PIPELINE_AUTO,
                   frames_in_flight=0):
         self._check(N.host.lpth_renderer_configure(self._h, seed, max_bounces, bsdf_mode, pipeline, frames_in_flight))

@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <memory>
 #include <string>
+#include <thread>
 
 #include "glibc_rand.hpp"
 #include "pt_scene_converter.hpp"
@@ -22,6 +23,13 @@ struct SceneHandle {
 struct RendererHandle {
   std::unique_ptr<RendererPT> renderer;
   lsg::Ref<lsg::Scene> scene;
+  // loadScene on a thread of its own, as src/Main.cpp:45 runs it
+  std::thread loadThread;
+  int loadStatus = 0;
+  std::string loadError;
+  ~RendererHandle() {
+    if (loadThread.joinable()) loadThread.join();
+  }
 };
 
 template <typename F>
@@ -136,6 +144,40 @@ int lpth_renderer_load_gltf(void* r, const char* path, int builder) {
     h->renderer->loadScene(h->scene);
   });
 }
+
+// Starts loading on a second host thread and returns at once (src/Main.cpp:45); the caller may spin
+// lpth_renderer_draw_frame meanwhile, which does nothing until the scene is in place
+// (src/RendererPT.cpp:608-612).  lpth_renderer_load_wait joins the thread and returns its status.
+int lpth_renderer_load_gltf_async(void* r, const char* path, int builder) {
+  return guarded([&] {
+    auto* h = (RendererHandle*)r;
+    if (h->loadThread.joinable()) throw std::runtime_error("a load is already running");
+    h->loadStatus = 0;
+    h->loadError.clear();
+    std::string file(path);
+    h->loadThread = std::thread([h, file, builder] {
+      try {
+        lsg::GLTFLoader loader;
+        h->scene = loader.load(file).at(0);
+        h->renderer->setMeshBuilder((PTSceneConverter::MeshBuilder)builder);
+        h->renderer->loadScene(h->scene);
+      } catch (const std::exception& e) {
+        h->loadStatus = -1;
+        h->loadError = e.what();
+      } catch (...) {
+        h->loadStatus = -1;
+        h->loadError = "unknown C++ exception";
+      }
+    });
+  });
+}
+int lpth_renderer_load_wait(void* r) {
+  auto* h = (RendererHandle*)r;
+  if (h->loadThread.joinable()) h->loadThread.join();
+  if (h->loadStatus != 0) g_error = h->loadError;
+  return h->loadStatus;
+}
+int lpth_renderer_scene_loaded(void* r) { return ((RendererHandle*)r)->renderer->sceneLoaded() ? 1 : 0; }
 
 int lpth_renderer_configure(void* r, uint32_t seed, int max_bounces, int bsdf_mode, int pipeline, int frames_in_flight) {
   return guarded([&] {

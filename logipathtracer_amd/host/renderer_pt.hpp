@@ -39,6 +39,9 @@ class RendererPT : public RendererCore {
   void resolve(std::vector<float>& rgba);
   // Samples accumulated per pixel so far.
   uint32_t samples() const { return sampleCount - 1; }
+  // false from the start of loadScene until it has finished (loadScene may run on a second thread while
+  // the draw loop spins, src/Main.cpp:45,96); drawFrame does nothing meanwhile
+  bool sceneLoaded() const { return sceneLoaded_.load(); }
   const PTSceneConverter& sceneConverter() const { return sceneConverter_; }
   const lsg::Ref<lsg::Transform>& cameraTransform() const { return selectedCameraTransform_; }
 

@@ -355,3 +355,48 @@ def test_persistent_launch_out_of_rounds_is_reported(cornell, cornell_oracle):
             assert np.array_equal(dev.read_accum(), ref)
     finally:
         dev.close()
+
+
+def test_scene_loads_on_a_second_thread_while_the_draw_loop_spins(tmp_path, cornell, cornell_oracle):
+    """src/Main.cpp:45,96: loadScene runs on a thread of its own while the main loop calls drawFrame, which
+    must render nothing until the scene is in place (src/RendererPT.cpp:608-612) — and what it renders
+    afterwards is what a serial load would have given."""
+    from logipathtracer_amd import scenes
+    w, h, bounces = 160, 90, 5
+    big = str(tmp_path / "outside.gltf")
+    scenes.write_outside_synth(big, 0.3)  # takes the builder a moment
+    for path, builder in ((CORNELL, L.BUILDER_SPLIT_BVH), (big, L.BUILDER_SPLIT_BVH)):
+        r = L.Renderer(w, h)
+        r.configure(seed=0x5EED, max_bounces=bounces)
+        r.load_scene_async(path, builder)
+        spins = 0
+        while not r.scene_loaded:
+            r.draw_frame()                 # no-op: no scene yet
+            assert r.samples == 0 or r.scene_loaded
+            spins += 1
+        r.wait_for_scene()
+        assert spins > 0
+        for _ in range(3):
+            r.draw_frame()
+        assert r.samples == 3
+        threaded = r.read_accumulation()
+        r.close()
+        serial = L.Renderer(w, h)
+        serial.configure(seed=0x5EED, max_bounces=bounces)
+        serial.load_scene(path, builder)
+        for _ in range(3):
+            serial.draw_frame()
+        assert np.array_equal(threaded, serial.read_accumulation())
+        serial.close()
+        if path == CORNELL:
+            ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, 3, seed=0x5EED)
+            ref, _ = O.render_frames(cornell_oracle, ubos, w, h, bounces)
+            assert np.array_equal(threaded, ref)
+    # a failing load on the thread is reported by the wait, and the renderer stays usable
+    r = L.Renderer(w, h)
+    r.load_scene_async(str(tmp_path / "missing.gltf"))
+    with pytest.raises(L.LptError, match="failed to open"):
+        r.wait_for_scene()
+    r.draw_frame()
+    assert r.samples == 0
+    r.close()
