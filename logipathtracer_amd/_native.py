@@ -121,6 +121,8 @@ _sig(host, "lpth_renderer_load_gltf", _i, _vp, C.c_char_p, _i)
 _sig(host, "lpth_renderer_load_gltf_async", _i, _vp, C.c_char_p, _i)
 _sig(host, "lpth_renderer_load_wait", _i, _vp)
 _sig(host, "lpth_renderer_scene_loaded", _i, _vp)
+_sig(host, "lpth_renderer_set_deferred_frames", _i, _vp, _u32)
+_sig(host, "lpth_renderer_flush", _i, _vp)
 _sig(host, "lpth_renderer_configure", _i, _vp, _u32, _i, _i, _i, _i)
 _sig(host, "lpth_renderer_draw_frame", _i, _vp)
 _sig(host, "lpth_renderer_draw_frames", _i, _vp, _u32)

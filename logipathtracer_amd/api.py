@@ -274,6 +274,13 @@ class Renderer:
                   frames_in_flight=0):
         self._check(N.host.lpth_renderer_configure(self._h, seed, max_bounces, bsdf_mode, pipeline, frames_in_flight))
 
+    def set_deferred_frames(self, n):
+        """drawFrame() queues frames and renders them `n` at a time (1 = render inside every call)."""
+        self._check(N.host.lpth_renderer_set_deferred_frames(self._h, int(n)))
+
+    def flush(self):
+        self._check(N.host.lpth_renderer_flush(self._h))
+
     def draw_frame(self):
         self._check(N.host.lpth_renderer_draw_frame(self._h))
 

@@ -998,7 +998,9 @@ void launch_shade(lpt_ctx* c, const Queue& in, const Queue& out, uint32_t b, uin
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, 0) != hipSuccess || n < 1) n = 4;
     return n;
   }();
-  hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, resident)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
+  static const int capPerCU = std::getenv("LPT_SHADE_BLOCKS_PER_CU") ? std::atoi(std::getenv("LPT_SHADE_BLOCKS_PER_CU")) : 0;
+  const int perCU = capPerCU > 0 ? std::min(resident, capPerCU) : resident;
+  hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, perCU)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
                      c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
 }
 

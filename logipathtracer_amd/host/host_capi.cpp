@@ -189,6 +189,12 @@ int lpth_renderer_configure(void* r, uint32_t seed, int max_bounces, int bsdf_mo
   });
 }
 
+int lpth_renderer_set_deferred_frames(void* r, uint32_t n) {
+  return guarded([&] { ((RendererHandle*)r)->renderer->setDeferredFrames(n); });
+}
+int lpth_renderer_flush(void* r) {
+  return guarded([&] { ((RendererHandle*)r)->renderer->flush(); });
+}
 int lpth_renderer_draw_frame(void* r) {
   return guarded([&] { ((RendererHandle*)r)->renderer->drawFrame(); });
 }

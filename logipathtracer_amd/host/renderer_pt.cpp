@@ -20,17 +20,33 @@ void RendererPT::applyOptions() {
   check(lpt_set_options(device_, maxTraceDepth_, bsdfMode_, pipeline_, framesInFlight_), "lpt_set_options");
 }
 
+void RendererPT::setDeferredFrames(uint32_t n) {
+  flush();
+  deferredFrames_ = n == 0 ? 1u : n;
+}
+
+void RendererPT::flush() {
+  if (batching_ || pending_.empty()) return;
+  // the queue is emptied first: a failing batch must not be submitted again by the next flush
+  std::vector<PathTracerUBO> frames;
+  frames.swap(pending_);
+  check(lpt_render_frames(device_, frames.data(), (int)frames.size()), "lpt_render_frames");
+}
+
 void RendererPT::setMaxTraceDepth(int bounces) {
+  flush();  // frames queued so far were drawn under the old options
   maxTraceDepth_ = bounces;
   applyOptions();
 }
 
 void RendererPT::setBsdfMode(int mode) {
+  flush();
   bsdfMode_ = mode;
   applyOptions();
 }
 
 void RendererPT::setPipeline(int pipeline, int framesInFlight) {
+  flush();
   pipeline_ = pipeline;
   framesInFlight_ = framesInFlight;
   applyOptions();
@@ -38,6 +54,7 @@ void RendererPT::setPipeline(int pipeline, int framesInFlight) {
 
 void RendererPT::loadScene(const lsg::Ref<lsg::Scene>& scene) {
   sceneLoaded_ = false;
+  flush();  // frames of the previous scene still queued
 
   sceneConverter_.loadScene(scene);
   const auto& cameras = sceneConverter_.getCameras();
@@ -59,7 +76,9 @@ void RendererPT::loadScene(const lsg::Ref<lsg::Scene>& scene) {
 }
 
 void RendererPT::onSwapChainRecreate() {
-  // a new target size restarts accumulation (src/RendererPT.cpp:225-232)
+  // a new target size restarts accumulation (src/RendererPT.cpp:225-232); frames still queued belonged to
+  // the old image and are dropped with it
+  pending_.clear();
   initializeAccumulationTexture();
   sampleCount = 1;
   ubo_.reset = 1u;
@@ -85,8 +104,9 @@ void RendererPT::preDraw() {
 }
 
 void RendererPT::submitFrame() {
-  if (batching_) {
+  if (batching_ || deferredFrames_ > 1) {
     pending_.push_back(ubo_);
+    if (!batching_ && pending_.size() >= deferredFrames_) flush();
     return;
   }
   check(lpt_render_frame(device_, &ubo_), "lpt_render_frame");
@@ -111,8 +131,8 @@ void RendererPT::drawFrame() {
 
 void RendererPT::drawFrames(uint32_t n) {
   if (!sceneLoaded_ || n == 0) return;
+  flush();
   batching_ = true;
-  pending_.clear();
   try {
     for (uint32_t i = 0; i < n; ++i) RendererCore::drawFrame();
   } catch (...) {
@@ -120,16 +140,17 @@ void RendererPT::drawFrames(uint32_t n) {
     throw;
   }
   batching_ = false;
-  check(lpt_render_frames(device_, pending_.data(), (int)pending_.size()), "lpt_render_frames");
-  pending_.clear();
+  flush();
 }
 
 void RendererPT::readAccumulation(std::vector<float>& rgba) {
+  flush();
   rgba.resize((size_t)renderWidth_ * renderHeight_ * 4);
   check(lpt_read_accum(device_, rgba.data()), "lpt_read_accum");
 }
 
 void RendererPT::resolve(std::vector<float>& rgba) {
+  flush();
   rgba.resize((size_t)renderWidth_ * renderHeight_ * 4);
   // the display pass divides by the number of samples accumulated so far
   float inv = samples() > 0 ? 1.0f / (float)samples() : 1.0f;

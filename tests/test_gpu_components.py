@@ -376,9 +376,9 @@ def test_scene_loads_on_a_second_thread_while_the_draw_loop_spins(tmp_path, corn
             spins += 1
         r.wait_for_scene()
         assert spins > 0
-        for _ in range(3):
+        assert r.samples <= 1  # the call that saw the scene arrive may already have drawn the first frame
+        while r.samples < 3:
             r.draw_frame()
-        assert r.samples == 3
         threaded = r.read_accumulation()
         r.close()
         serial = L.Renderer(w, h)
@@ -400,3 +400,46 @@ def test_scene_loads_on_a_second_thread_while_the_draw_loop_spins(tmp_path, corn
     r.draw_frame()
     assert r.samples == 0
     r.close()
+
+
+def test_deferred_submission_renders_the_same_image(cornell):
+    """RendererPT::setDeferredFrames: drawFrame() queues frames and renders them in batches; every observation
+    (read, resolve) and every change later frames depend on (camera, options, size) sees the same image as the
+    reference's frame-by-frame submission."""
+    w, h = 144, 80
+
+    def script(r):
+        out = []
+        r.configure(seed=77, max_bounces=5)
+        r.load_scene(CORNELL)
+        for _ in range(7):
+            r.draw_frame()
+        out.append((r.samples, r.read_accumulation()))
+        r.move_camera(0, 0.25)            # restarts accumulation in the middle of a queue
+        for _ in range(5):
+            r.draw_frame()
+        r.move_camera(4, 0.1)
+        for _ in range(3):
+            r.draw_frame()
+        out.append((r.samples, r.resolve()))
+        r.configure(seed=78, max_bounces=3)   # option change: queued frames keep the old depth
+        for _ in range(4):
+            r.draw_frame()
+        out.append((r.samples, r.read_accumulation()))
+        r.resize(96, 64)
+        r.draw_frame()
+        r.draw_frames(3)
+        out.append((r.samples, r.read_accumulation()))
+        return out
+
+    a = L.Renderer(w, h)
+    want = script(a)
+    a.close()
+    for n in (4, 64):
+        b = L.Renderer(w, h)
+        b.set_deferred_frames(n)
+        got = script(b)
+        b.close()
+        assert [s for s, _ in got] == [s for s, _ in want] == [7, 3, 7, 4]
+        for (_, x), (_, y) in zip(got, want):
+            assert x.shape == y.shape and np.array_equal(x, y), n
