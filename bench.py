@@ -360,6 +360,7 @@ def main():
         else:
             counters = traversal_counters(scene, ubos, args.width, args.height, args.bounces)
         result["cpu_baseline"] = cpu
+        result["kernel_segments"] = float(kernel_seg_total)  # segments traced by the launches extend_ms times
         result["roofline"] = roofline(args, scene, ubos, counters, used_pipeline, kernel_seg_total, ext_ms, ext_launches,
                                       torch.cuda.get_device_properties(device_index)) if counters and ext_ms > 0 else None
         print(json.dumps(result))

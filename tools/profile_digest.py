@@ -59,7 +59,7 @@ for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_tr
     segs, pipe = None, None
     try:
         b = json.load(open(os.path.join(src, "fetch.json")))
-        segs = b.get("kernel_segments", b["traced_segments"]) / b["extend_launches_rank0"]
+        segs = (b.get("roofline") or {}).get("segments_per_launch") or b["kernel_segments"] / b["extend_launches_rank0"]
         pipe = {"wavefront": 0, "persistent": 2, "hybrid": 4}.get(b["config"]["pipeline"].split()[0])
     except Exception:
         pass
