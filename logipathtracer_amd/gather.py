@@ -3,7 +3,7 @@
 Each rank accumulates its tiles in the compact buffer lpt_owned_accum_device points at (equal size on
 every rank).  After rendering, one `all_gather_into_tensor` (RCCL over xGMI with the "nccl" backend)
 delivers all buffers to every rank and lpt_assemble_gathered scatters them into a scan-line image.
-torch is used for the process group and for device memory only; the buffer is aliased, not copied.
+torch is used for the process group and for device memory only.
 """
 import time
 
@@ -29,10 +29,12 @@ def gather_image(dev, world, width, height, torch_device, backend="nccl"):
     host memory."""
     import torch
     import torch.distributed as dist
-    mine = owned_accum_tensor(dev, torch_device)
+    dev.synchronize()
+    # The collective reads a torch-owned copy of the compact buffer (16 bytes per owned pixel: a few tens of MB):
+    # RCCL then only ever sees memory of the allocator it is tested with, never the library's own hipMalloc block.
+    mine = owned_accum_tensor(dev, torch_device).clone()
     n_floats = mine.numel()
     gathered = torch.empty(world * n_floats, dtype=torch.float32, device=torch_device)
-    dev.synchronize()
     torch.cuda.synchronize(torch_device)
     dist.barrier()
     t0 = time.perf_counter()
