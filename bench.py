@@ -248,8 +248,7 @@ def main():
         args.scene = os.path.join(sdir, "outside_synth.gltf")
         _scenes.write_outside_synth(args.scene, 1.0)
     dev = L.Device(device_index)
-    scene = L.Scene(args.scene, builder=args.builder if args.builder != L.BUILDER_LBVH else L.BUILDER_LBVH,
-                    device=dev if args.builder == L.BUILDER_LBVH else None)
+    scene = L.Scene(args.scene, builder=args.builder, device=dev if args.builder in L.GPU_BUILDERS else None)
     dev.upload_scene(scene)
     dev.resize(args.width, args.height)
     if world > 1:
@@ -340,7 +339,7 @@ def main():
                 "workload": f"{os.path.basename(args.scene)} {args.width}x{args.height}, {args.bounces} bounces, "
                             f"Heitz BSDF, {spp_step} spp per step ({args.spp_per_step} per GPU)",
                 "spp_per_step": spp_step, "tile": args.tile if world > 1 else None,
-                "builder": ["split_bvh", "binned_sah", "lbvh_gpu"][args.builder],
+                "builder": ["split_bvh", "binned_sah", "lbvh_gpu", "ploc_gpu"][args.builder],
                 "pipeline": ["wavefront", "megakernel", "persistent", "auto", "hybrid"][used_pipeline]
                             + (" (chosen automatically)" if args.pipeline == 3 else ""),
             },

@@ -112,7 +112,10 @@ enum {
   LPT_PIPELINE_HYBRID = 4
 };
 /* Mesh BVH builders offered by lpt_build_mesh_bvh. */
-enum { LPT_BVH_LBVH = 0 };
+enum {
+  LPT_BVH_LBVH = 0, /* Morton codes, radix sort, radix-tree hierarchy */
+  LPT_BVH_PLOC = 1  /* Morton order, then bottom-up clustering by merged surface area: SAH-class trees */
+};
 
 typedef struct lpt_ctx lpt_ctx;
 

@@ -7,7 +7,8 @@ from . import _native as N
 
 BSDF_HEITZ, BSDF_BASIC = 0, 1
 PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_PERSISTENT, PIPELINE_AUTO, PIPELINE_HYBRID = 0, 1, 2, 3, 4
-BUILDER_SPLIT_BVH, BUILDER_BINNED_SAH, BUILDER_LBVH = 0, 1, 2
+BUILDER_SPLIT_BVH, BUILDER_BINNED_SAH, BUILDER_LBVH, BUILDER_PLOC = 0, 1, 2, 3
+GPU_BUILDERS = (BUILDER_LBVH, BUILDER_PLOC)
 
 
 class LptError(RuntimeError):
@@ -200,14 +201,14 @@ class Device:
     def assemble_gathered(self, gathered_ptr, n_ranks, image_ptr):
         self._check(N.hip.lpt_assemble_gathered(self._ctx, C.c_void_p(gathered_ptr), n_ranks, C.c_void_p(image_ptr)))
 
-    def build_mesh_bvh(self, corners):
-        """corners: (n,3,3) float32 triangle corners -> (nodes, triangle order)."""
+    def build_mesh_bvh(self, corners, builder=0):
+        """corners: (n,3,3) float32 triangle corners -> (nodes, triangle order).  builder: 0 LBVH, 1 PLOC."""
         corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 9)
         n = len(corners)
         nodes = np.zeros(max(1, 2 * n), dtype=N.NODE_DTYPE)
         order = np.zeros(max(1, n), dtype=np.uint32)
         cnt = C.c_uint32()
-        self._check(N.hip.lpt_build_mesh_bvh(self._ctx, 0, _ptr(corners), n, _ptr(nodes), C.byref(cnt), _ptr(order)))
+        self._check(N.hip.lpt_build_mesh_bvh(self._ctx, int(builder), _ptr(corners), n, _ptr(nodes), C.byref(cnt), _ptr(order)))
         return nodes[:cnt.value].copy(), order[:n].copy()
 
     def debug_set_trace_round_limit(self, rounds):

@@ -1,11 +1,15 @@
-// Linear BVH construction on the GPU for one triangle mesh:
-//   triangle boxes + mesh bounds -> 30-bit Morton codes of the box centres ->
-//   radix sort (rocPRIM) -> radix-tree hierarchy (Karras, "Maximizing Parallelism in the
+// BVH construction on the GPU for one triangle mesh.  Both builders start alike:
+//   triangle boxes + mesh bounds -> 30-bit Morton codes of the box centres -> radix sort (rocPRIM).
+// LPT_BVH_LBVH: radix-tree hierarchy over the sorted codes (Karras, "Maximizing Parallelism in the
 //   Construction of BVHs, Octrees, and k-d Trees", 2012) -> bottom-up box fitting.
-// The fitted tree is then written out on the host in depth-first order as interchange
-// nodes (include/lpt.h: lpt_bvh_node), with subtrees of at most kLeafSize triangles
-// collapsed into leaves.  Stands in for lsg::bvh::SplitBVHBuilder at
-// src/PTSceneConverter.cpp:97-101 of the reference.
+// LPT_BVH_PLOC: bottom-up agglomeration of the sorted triangles (Meister & Bittner, "Parallel Locally-
+//   Ordered Clustering for Bounding Volume Hierarchy Construction", 2018): every cluster looks kPlocRadius
+//   places to either side along the Morton curve for the neighbour with which it forms the smallest box,
+//   mutual choices merge, the cluster list is compacted, until one cluster is left.  The tree follows the
+//   geometry (surface area of the merged boxes) instead of the bits of the codes: SAH-class quality.
+// The tree is then written out on the host in depth-first order as interchange nodes (include/lpt.h:
+// lpt_bvh_node), with subtrees of at most kLeafSize triangles collapsed into leaves.  Stands in for
+// lsg::bvh::SplitBVHBuilder at src/PTSceneConverter.cpp:97-101 of the reference.
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -171,6 +175,100 @@ __global__ void k_copy_flags(const uint32_t* __restrict__ src, uint32_t* __restr
   if (i < n) dst[i] = src[i];
 }
 
+// ---- PLOC ------------------------------------------------------------------------------------
+
+constexpr int kPlocRadius = 16;
+
+__device__ __forceinline__ float union_area(const float* __restrict__ nodeMin, const float* __restrict__ nodeMax,
+                                            uint32_t a, uint32_t b) {
+  float d[3];
+  for (int k = 0; k < 3; ++k)
+    d[k] = fmaxf(nodeMax[3 * (size_t)a + k], nodeMax[3 * (size_t)b + k]) -
+           fminf(nodeMin[3 * (size_t)a + k], nodeMin[3 * (size_t)b + k]);
+  return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+}
+
+// nn[i] = the position j in [i-r, i+r], j != i, whose cluster forms the smallest box with cluster i.  Pairs
+// are ranked by (area, lower position, higher position): a total order that both members of a pair see
+// alike, so the best pair of the whole list always chooses each other and every round merges something.
+__global__ void k_ploc_nearest(const uint32_t* __restrict__ cid, uint32_t m, const float* __restrict__ nodeMin,
+                               const float* __restrict__ nodeMax, uint32_t* __restrict__ nn) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t me = cid[i];
+  const uint32_t lo = i > (uint32_t)kPlocRadius ? i - kPlocRadius : 0u;
+  const uint32_t hi = min(m - 1u, i + (uint32_t)kPlocRadius);
+  float best = INFINITY;
+  uint32_t bestJ = i + 1u < m ? i + 1u : i - 1u;  // some neighbour even if every area is NaN
+  uint32_t bestLo = min(i, bestJ), bestHi = max(i, bestJ);
+  bool have = false;
+  for (uint32_t j = lo; j <= hi; ++j) {
+    if (j == i) continue;
+    const float a = union_area(nodeMin, nodeMax, me, cid[j]);
+    const uint32_t pl = min(i, j), ph = max(i, j);
+    const bool better = !have ? (a == a) : (a < best || (a == best && (pl < bestLo || (pl == bestLo && ph < bestHi))));
+    if (better) {
+      best = a;
+      bestJ = j;
+      bestLo = pl;
+      bestHi = ph;
+      have = true;
+    }
+  }
+  nn[i] = bestJ;
+}
+
+// leader[i] = 1 where i and nn[i] chose each other and i is the lower position (it will hold the merged
+// cluster); valid[i] = 0 for the higher position of such a pair (it disappears), 1 otherwise.
+// `pairUp`: a round without any mutual choice (possible only with non-finite boxes) pairs neighbours instead.
+__global__ void k_ploc_flags(uint32_t* __restrict__ nn, uint32_t m, uint32_t* __restrict__ leader,
+                             uint32_t* __restrict__ valid, int pairUp) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  uint32_t j = nn[i];
+  bool mutual = nn[j] == i;
+  if (pairUp) {
+    j = (i & 1u) ? i - 1u : i + 1u;
+    mutual = j < m;
+  }
+  leader[i] = (mutual && i < j) ? 1u : 0u;
+  valid[i] = (mutual && i > j) ? 0u : 1u;
+}
+__global__ void k_ploc_pair_up(uint32_t* __restrict__ nn, uint32_t m) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t j = (i & 1u) ? i - 1u : i + 1u;
+  nn[i] = j < m ? j : i;  // the odd one out keeps itself: never mutual with anyone
+}
+
+// Leaders create their inner node (ids count up from nextId in list order: the numbering does not depend on
+// scheduling) and everyone still valid moves to its place in the compacted list.
+__global__ void k_ploc_merge(const uint32_t* __restrict__ cid, const uint32_t* __restrict__ nn, uint32_t m,
+                             const uint32_t* __restrict__ leader, const uint32_t* __restrict__ leaderRank,
+                             const uint32_t* __restrict__ valid, const uint32_t* __restrict__ validRank, uint32_t nextId,
+                             uint32_t* __restrict__ left, uint32_t* __restrict__ right, float* __restrict__ nodeMin,
+                             float* __restrict__ nodeMax, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || !valid[i]) return;
+  uint32_t id = cid[i];
+  if (leader[i]) {
+    const uint32_t a = cid[i], b = cid[nn[i]];
+    id = nextId + leaderRank[i];
+    left[id] = a;
+    right[id] = b;
+    for (int k = 0; k < 3; ++k) {
+      nodeMin[3 * (size_t)id + k] = fminf(nodeMin[3 * (size_t)a + k], nodeMin[3 * (size_t)b + k]);
+      nodeMax[3 * (size_t)id + k] = fmaxf(nodeMax[3 * (size_t)a + k], nodeMax[3 * (size_t)b + k]);
+    }
+  }
+  out[validRank[i]] = id;
+}
+
+__global__ void k_ploc_init(uint32_t* __restrict__ cid, uint32_t n) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) cid[j] = n - 1u + j;  // leaf ids, in Morton order
+}
+
 void put_box(lpt_bvh_node& g, const float* mn, const float* mx) {
   for (int k = 0; k < 3; ++k) {
     g.minCorner[k] = mn[k];
@@ -183,7 +281,7 @@ void put_box(lpt_bvh_node& g, const float* mn, const float* mx) {
 extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positions, uint32_t n,
                                   lpt_bvh_node* nodesOut, uint32_t* nNodesOut, uint32_t* primOrderOut) {
   if (!ctx) return LPT_ERR_INVALID;
-  if (builder != LPT_BVH_LBVH) return lpt_internal_fail(ctx, LPT_ERR_INVALID, "unknown BVH builder");
+  if (builder != LPT_BVH_LBVH && builder != LPT_BVH_PLOC) return lpt_internal_fail(ctx, LPT_ERR_INVALID, "unknown BVH builder");
   if (!nodesOut || !nNodesOut || (n && (!positions || !primOrderOut)))
     return lpt_internal_fail(ctx, LPT_ERR_INVALID, "null argument");
   if (n >= (1u << 30)) return lpt_internal_fail(ctx, LPT_ERR_INVALID, "too many triangles");
@@ -201,9 +299,13 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
   uint32_t *dLeft = nullptr, *dRight = nullptr, *dLo = nullptr, *dHi = nullptr, *dReadyA = nullptr, *dReadyB = nullptr;
   uint32_t* dRemaining = nullptr;
   void* dTemp = nullptr;
+  uint32_t *dCidA = nullptr, *dCidB = nullptr, *dNn = nullptr, *dLeader = nullptr, *dValid = nullptr, *dLeaderRank = nullptr,
+           *dValidRank = nullptr;
+  void* dScanTemp = nullptr;
   auto release = [&]() {
     void* ptrs[] = {dPos, dBoxMin, dBoxMax, dNodeMin, dNodeMax, dBounds, dCodes, dIds, dCodesS, dIdsS,
-                    dLeft, dRight, dLo, dHi, dReadyA, dReadyB, dRemaining, dTemp};
+                    dLeft, dRight, dLo, dHi, dReadyA, dReadyB, dRemaining, dTemp,
+                    dCidA, dCidB, dNn, dLeader, dValid, dLeaderRank, dValidRank, dScanTemp};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
   };
@@ -243,13 +345,67 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
   LB_HIP(ctx, rocprim::radix_sort_pairs(dTemp, tempBytes, dCodes, dCodesS, dIds, dIdsS, n, 0, 30, stream));
 
   LB_HIP(ctx, hipMemsetAsync(dReadyA, 0, (size_t)nNodes * sizeof(uint32_t), stream));
-  if (nInternal)
+  if (nInternal && builder == LPT_BVH_LBVH)
     hipLaunchKernelGGL(k_hierarchy, dim3((nInternal + B - 1) / B), dim3(B), 0, stream, dCodesS, (int)n, dLeft, dRight, dLo, dHi);
   hipLaunchKernelGGL(k_leaf_boxes, dim3((n + B - 1) / B), dim3(B), 0, stream, dBoxMin, dBoxMax, dIdsS, n, dNodeMin, dNodeMax, dReadyA);
   LB_HIP(ctx, hipGetLastError());
 
-  // bottom-up sweeps until every internal node has its box (at most tree-depth sweeps)
-  uint32_t remaining = nInternal;
+  uint32_t rootId = nInternal ? 0u : n - 1u;  // LBVH: internal node 0; a single triangle: its leaf
+  if (builder == LPT_BVH_PLOC && nInternal) {
+    // agglomeration rounds; internal ids are handed out in creation order, the last one created is the root
+    LB_HIP(ctx, hipMalloc(&dCidA, n * sizeof(uint32_t)));
+    LB_HIP(ctx, hipMalloc(&dCidB, n * sizeof(uint32_t)));
+    LB_HIP(ctx, hipMalloc(&dNn, n * sizeof(uint32_t)));
+    LB_HIP(ctx, hipMalloc(&dLeader, n * sizeof(uint32_t)));
+    LB_HIP(ctx, hipMalloc(&dValid, n * sizeof(uint32_t)));
+    LB_HIP(ctx, hipMalloc(&dLeaderRank, n * sizeof(uint32_t)));
+    LB_HIP(ctx, hipMalloc(&dValidRank, n * sizeof(uint32_t)));
+    size_t scanBytes = 0;
+    LB_HIP(ctx, rocprim::exclusive_scan(nullptr, scanBytes, dLeader, dLeaderRank, 0u, n, rocprim::plus<uint32_t>(), stream));
+    LB_HIP(ctx, hipMalloc(&dScanTemp, std::max<size_t>(scanBytes, 16)));
+    hipLaunchKernelGGL(k_ploc_init, dim3((n + B - 1) / B), dim3(B), 0, stream, dCidA, n);
+    uint32_t m = n, nextId = 0;
+    uint32_t* cur = dCidA;
+    uint32_t* nxt = dCidB;
+    for (int round = 0; m > 1; ++round) {
+      if (round > 8192) {
+        release();
+        return lpt_internal_fail(ctx, LPT_ERR_INVALID, "PLOC clustering did not converge");
+      }
+      const dim3 grid((m + B - 1) / B);
+      hipLaunchKernelGGL(k_ploc_nearest, grid, dim3(B), 0, stream, cur, m, dNodeMin, dNodeMax, dNn);
+      uint32_t tail[4] = {0, 0, 0, 0};  // last leader rank and flag, last valid rank and flag
+      for (int pairUp = 0; pairUp < 2; ++pairUp) {
+        if (pairUp) hipLaunchKernelGGL(k_ploc_pair_up, grid, dim3(B), 0, stream, dNn, m);
+        hipLaunchKernelGGL(k_ploc_flags, grid, dim3(B), 0, stream, dNn, m, dLeader, dValid, 0);
+        LB_HIP(ctx, hipGetLastError());
+        LB_HIP(ctx, rocprim::exclusive_scan(dScanTemp, scanBytes, dLeader, dLeaderRank, 0u, m, rocprim::plus<uint32_t>(), stream));
+        LB_HIP(ctx, rocprim::exclusive_scan(dScanTemp, scanBytes, dValid, dValidRank, 0u, m, rocprim::plus<uint32_t>(), stream));
+        LB_HIP(ctx, hipMemcpyAsync(&tail[0], dLeaderRank + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LB_HIP(ctx, hipMemcpyAsync(&tail[1], dLeader + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LB_HIP(ctx, hipMemcpyAsync(&tail[2], dValidRank + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LB_HIP(ctx, hipMemcpyAsync(&tail[3], dValid + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        LB_HIP(ctx, hipStreamSynchronize(stream));
+        if (tail[0] + tail[1] > 0) break;  // something merges; otherwise (non-finite boxes only) pair up neighbours
+      }
+      const uint32_t merges = tail[0] + tail[1], survivors = tail[2] + tail[3];
+      if (merges == 0 || survivors != m - merges || nextId + merges > nInternal) {
+        release();
+        return lpt_internal_fail(ctx, LPT_ERR_INVALID, "PLOC clustering made no progress");
+      }
+      hipLaunchKernelGGL(k_ploc_merge, grid, dim3(B), 0, stream, cur, dNn, m, dLeader, dLeaderRank, dValid, dValidRank, nextId,
+                         dLeft, dRight, dNodeMin, dNodeMax, nxt);
+      LB_HIP(ctx, hipGetLastError());
+      nextId += merges;
+      m = survivors;
+      std::swap(cur, nxt);
+    }
+    LB_HIP(ctx, hipStreamSynchronize(stream));
+    rootId = nextId - 1u;  // == nInternal - 1
+  }
+
+  // LBVH: bottom-up sweeps until every internal node has its box (at most tree-depth sweeps)
+  uint32_t remaining = builder == LPT_BVH_LBVH ? nInternal : 0u;
   uint32_t* in = dReadyA;
   uint32_t* out = dReadyB;
   for (int sweep = 0; remaining != 0; ++sweep) {
@@ -267,24 +423,50 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
     std::swap(in, out);
   }
 
-  std::vector<uint32_t> left(nInternal), right(nInternal), lo(nInternal), hi(nInternal);
+  std::vector<uint32_t> left(nInternal), right(nInternal), sorted(n);
   std::vector<float> nodeMin(3 * (size_t)nNodes), nodeMax(3 * (size_t)nNodes);
   if (nInternal) {
     LB_HIP(ctx, hipMemcpy(left.data(), dLeft, nInternal * sizeof(uint32_t), hipMemcpyDeviceToHost));
     LB_HIP(ctx, hipMemcpy(right.data(), dRight, nInternal * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    LB_HIP(ctx, hipMemcpy(lo.data(), dLo, nInternal * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    LB_HIP(ctx, hipMemcpy(hi.data(), dHi, nInternal * sizeof(uint32_t), hipMemcpyDeviceToHost));
   }
   LB_HIP(ctx, hipMemcpy(nodeMin.data(), dNodeMin, nodeMin.size() * sizeof(float), hipMemcpyDeviceToHost));
   LB_HIP(ctx, hipMemcpy(nodeMax.data(), dNodeMax, nodeMax.size() * sizeof(float), hipMemcpyDeviceToHost));
-  LB_HIP(ctx, hipMemcpy(primOrderOut, dIdsS, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  LB_HIP(ctx, hipMemcpy(sorted.data(), dIdsS, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   release();
 
-  // depth-first write-out; a subtree spanning at most kLeafSize sorted triangles becomes a leaf
-  uint32_t count = 0;
+  // Triangles under every internal node (children before parents: iterative post-order); also rejects
+  // anything that is not a tree over all n leaves.
+  std::vector<uint32_t> tris(nInternal, 0u);
+  {
+    std::vector<uint32_t> order;
+    order.reserve(nInternal);
+    std::vector<uint32_t> walk;
+    if (rootId < nInternal) walk.push_back(rootId);
+    while (!walk.empty()) {
+      const uint32_t i = walk.back();
+      walk.pop_back();
+      order.push_back(i);
+      if (order.size() > nInternal) return lpt_internal_fail(ctx, LPT_ERR_INVALID, "GPU BVH build produced a malformed tree");
+      for (uint32_t ch : {left[i], right[i]}) {
+        if (ch >= nNodes) return lpt_internal_fail(ctx, LPT_ERR_INVALID, "GPU BVH build produced a malformed tree");
+        if (ch < nInternal) walk.push_back(ch);
+      }
+    }
+    for (size_t k = order.size(); k-- > 0;) {
+      const uint32_t i = order[k];
+      tris[i] = (left[i] < nInternal ? tris[left[i]] : 1u) + (right[i] < nInternal ? tris[right[i]] : 1u);
+    }
+    if ((rootId < nInternal ? tris[rootId] : 1u) != n)
+      return lpt_internal_fail(ctx, LPT_ERR_INVALID, "GPU BVH build produced a malformed tree");
+  }
+
+  // depth-first write-out; a subtree of at most kLeafSize triangles becomes a leaf whose triangles take the
+  // next places of the triangle order (for the radix tree that is the Morton order itself)
+  uint32_t count = 0, placed = 0;
   struct Item { uint32_t node; uint32_t parentSlot; int side; };
   std::vector<Item> st;
-  st.push_back({nInternal ? 0u : (n - 1), 0xFFFFFFFFu, 0});
+  std::vector<uint32_t> gather;
+  st.push_back({rootId, 0xFFFFFFFFu, 0});
   while (!st.empty()) {
     Item it = st.back();
     st.pop_back();
@@ -293,15 +475,21 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
     std::memset(&g, 0, sizeof g);
     put_box(g, &nodeMin[3 * (size_t)it.node], &nodeMax[3 * (size_t)it.node]);
     if (it.parentSlot != 0xFFFFFFFFu) nodesOut[it.parentSlot].indices[it.side] = slot;
-    if (it.node >= nInternal) {  // single triangle
-      uint32_t j = it.node - nInternal;
+    if (it.node >= nInternal || tris[it.node] <= kLeafSize) {
       g.isLeaf = 1u;
-      g.indices[0] = j;
-      g.indices[1] = j + 1;
-    } else if (hi[it.node] - lo[it.node] + 1 <= kLeafSize) {
-      g.isLeaf = 1u;
-      g.indices[0] = lo[it.node];
-      g.indices[1] = hi[it.node] + 1;
+      g.indices[0] = placed;
+      gather.assign(1, it.node);
+      while (!gather.empty()) {  // the subtree's triangles, left to right
+        const uint32_t v = gather.back();
+        gather.pop_back();
+        if (v >= nInternal) {
+          primOrderOut[placed++] = sorted[v - nInternal];
+        } else {
+          gather.push_back(right[v]);
+          gather.push_back(left[v]);
+        }
+      }
+      g.indices[1] = placed;
     } else {
       st.push_back({right[it.node], slot, 1});
       st.push_back({left[it.node], slot, 0});  // left is written next: first child follows its parent

@@ -53,7 +53,7 @@ const char* lpth_last_error() { return g_error.c_str(); }
 
 // ---- scene conversion (PTSceneConverter) ------------------------------------------------
 
-// builder: 0 SplitBVH (host), 1 BinnedSAH (host), 2 LBVH (GPU; needs ctx).  ctx may be NULL
+// builder: 0 SplitBVH (host), 1 BinnedSAH (host), 2 LBVH, 3 PLOC (GPU; need ctx).  ctx may be NULL
 // for host-only conversion; when given, the buffers are also uploaded to it.
 void* lpth_scene_load(const char* gltf_path, int builder, lpt_ctx* ctx) {
   SceneHandle* h = nullptr;

@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     else { std::cerr << "unknown option " << a << "\n"; return 2; }
   }
   if (scenePath.empty()) {
-    std::cerr << "usage: lpt_render scene.gltf [--width W --height H --spp N --bounces B --seed S --device D --basic-bsdf --wavefront | --megakernel | --persistent | --hybrid --builder 0|1|2 --out prefix]\n";
+    std::cerr << "usage: lpt_render scene.gltf [--width W --height H --spp N --bounces B --seed S --device D --basic-bsdf --wavefront | --megakernel | --persistent | --hybrid --builder 0|1|2|3 --out prefix]\n";
     return 2;
   }
   try {

@@ -107,8 +107,8 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
     auto uvAcc = job.geometry->hasUv(0u) ? job.geometry->getTriangleUVAccessor(0u) : nullptr;
     const uint32_t nTris = (uint32_t)posAcc->count();
     std::vector<uint32_t> order;
-    if (meshBuilder_ == MeshBuilder::LBVH) {
-      if (!device_) throw std::runtime_error("PTSceneConverter: the LBVH builder needs a device context");
+    if (meshBuilder_ == MeshBuilder::LBVH || meshBuilder_ == MeshBuilder::PLOC) {
+      if (!device_) throw std::runtime_error("PTSceneConverter: the GPU builders need a device context");
       std::vector<float> corners(9 * (size_t)nTris);
       for (uint32_t t = 0; t < nTris; ++t) {
         auto T = (*posAcc)[t];
@@ -123,7 +123,8 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
       job.nodes.resize(nTris ? 2 * (size_t)nTris : 1);
       order.resize(nTris);
       uint32_t nNodes = 0;
-      int rc = lpt_build_mesh_bvh(device_, LPT_BVH_LBVH, corners.data(), nTris, job.nodes.data(), &nNodes, order.data());
+      const int which = meshBuilder_ == MeshBuilder::PLOC ? LPT_BVH_PLOC : LPT_BVH_LBVH;
+      int rc = lpt_build_mesh_bvh(device_, which, corners.data(), nTris, job.nodes.data(), &nNodes, order.data());
       if (rc != LPT_OK) throw std::runtime_error(std::string("lpt_build_mesh_bvh: ") + lpt_last_error(device_));
       job.nodes.resize(nNodes);
     } else {
@@ -153,7 +154,7 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
   };
   // the GPU builder uses one device context: serial; the host builders run one job per thread at a time
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  const unsigned nThreads = meshBuilder_ == MeshBuilder::LBVH ? 1u : std::min<unsigned>(hw, (unsigned)std::max<size_t>(1, jobs.size()));
+  const unsigned nThreads = (meshBuilder_ == MeshBuilder::LBVH || meshBuilder_ == MeshBuilder::PLOC) ? 1u : std::min<unsigned>(hw, (unsigned)std::max<size_t>(1, jobs.size()));
   std::atomic<size_t> nextJob{0};
   auto worker = [&]() {
     for (size_t j; (j = nextJob.fetch_add(1)) < jobs.size();) {

@@ -31,7 +31,8 @@ class PTSceneConverter {
   enum class MeshBuilder {
     SplitBVH = 0,   // host SAH build with spatial splits
     BinnedSAH = 1,  // host SAH build, object splits only
-    LBVH = 2        // Morton-code build on the GPU (needs a device context)
+    LBVH = 2,       // Morton-code build on the GPU (needs a device context)
+    PLOC = 3        // GPU build by locally-ordered clustering: SAH-class quality (needs a device context)
   };
 
   // `device` may be null: buffers are then built on the host only.

@@ -60,7 +60,7 @@ def _random_rays(n, seed):
     return o, d
 
 
-@pytest.mark.parametrize("builder", [L.BUILDER_SPLIT_BVH, L.BUILDER_BINNED_SAH, L.BUILDER_LBVH])
+@pytest.mark.parametrize("builder", [L.BUILDER_SPLIT_BVH, L.BUILDER_BINNED_SAH, L.BUILDER_LBVH, L.BUILDER_PLOC])
 def test_traversal_matches_oracle_hit_for_hit(device, builder):
     s = L.Scene(CORNELL, builder=builder, device=device)
     osc = O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
@@ -76,13 +76,14 @@ def test_traversal_matches_oracle_hit_for_hit(device, builder):
     assert brute_miss <= 3  # the tree finds what a linear scan finds (up to slab-test rounding)
 
 
-def test_lbvh_tree_is_well_formed(device):
+@pytest.mark.parametrize("which", [0, 1], ids=["lbvh", "ploc"])
+def test_lbvh_tree_is_well_formed(device, which):
     rng = np.random.default_rng(3)
     for n in (1, 2, 3, 5, 64, 1000, 20011):
         c = rng.uniform(-1, 1, size=(n, 1, 3)).astype(F32) + rng.uniform(-0.05, 0.05, size=(n, 3, 3)).astype(F32)
         if n == 64:
-            c[:] = c[0]  # all triangles identical: every Morton code equal
-        nodes, order = device.build_mesh_bvh(c)
+            c[:] = c[0]  # all triangles identical: every Morton code equal, every merged box the same
+        nodes, order = device.build_mesh_bvh(c, which)
         assert sorted(order.tolist()) == list(range(n))
         assert 1 <= len(nodes) <= max(1, 2 * n - 1)
         seen = np.zeros(n, dtype=np.int32)
@@ -102,7 +103,10 @@ def test_lbvh_tree_is_well_formed(device):
                     assert np.all(chn["minCorner"] >= nd["minCorner"]) and np.all(chn["maxCorner"] <= nd["maxCorner"])
                     stack.append(int(ch))
         assert np.all(seen == 1)
-    nodes, order = device.build_mesh_bvh(np.zeros((0, 3, 3), F32))
+    # two builds of the same mesh give the same tree (node numbering does not depend on scheduling)
+    again, order2 = device.build_mesh_bvh(c, which)
+    assert np.array_equal(again, nodes) and np.array_equal(order2, order)
+    nodes, order = device.build_mesh_bvh(np.zeros((0, 3, 3), F32), which)
     assert len(nodes) == 1 and nodes[0]["isLeaf"] == 1 and nodes[0]["indices"][0] == nodes[0]["indices"][1]
 
 

@@ -45,7 +45,7 @@ def test_full_size_outside_synth_matches_the_reference_scene_shape(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("builder", [L.BUILDER_SPLIT_BVH, L.BUILDER_BINNED_SAH, L.BUILDER_LBVH])
+@pytest.mark.parametrize("builder", [L.BUILDER_SPLIT_BVH, L.BUILDER_BINNED_SAH, L.BUILDER_LBVH, L.BUILDER_PLOC])
 def test_outside_synth_parity(device, small_outside, builder):
     path, _ = small_outside
     s = L.Scene(path, builder=builder, device=device)

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import logipathtracer_amd as L  # noqa: E402
 from logipathtracer_amd import scenes  # noqa: E402
 
-NAMES = ["split_bvh", "binned_sah", "lbvh_gpu"]
+NAMES = ["split_bvh", "binned_sah", "lbvh_gpu", "ploc_gpu"]
 
 
 def main():
@@ -23,10 +23,10 @@ def main():
     cornell = os.path.join(ROOT, "tests", "golden", "cornell_box.gltf")
     dev = L.Device(0)
     for label, path, bench_scene, spp in (("cornell_box", cornell, cornell, 64), ("outside_synth", outside, "outside_synth", 16)):
-        for b in range(3):
-            L.Scene(path, builder=b, device=dev if b == L.BUILDER_LBVH else None)  # warm (first GPU build compiles nothing, but pages in)
+        for b in range(4):
+            L.Scene(path, builder=b, device=dev if b in L.GPU_BUILDERS else None)  # warm (first GPU build compiles nothing, but pages in)
             t0 = time.perf_counter()
-            s = L.Scene(path, builder=b, device=dev if b == L.BUILDER_LBVH else None)
+            s = L.Scene(path, builder=b, device=dev if b in L.GPU_BUILDERS else None)
             build_s = time.perf_counter() - t0
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", bench_scene, "--builder", str(b),
                                 "--steps", "3", "--warmup", "1", "--spp-per-step", str(spp), "--no-cpu-baseline"],
