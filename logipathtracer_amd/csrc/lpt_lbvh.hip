@@ -24,7 +24,10 @@
 
 namespace {
 
-constexpr uint32_t kLeafSize = 4;
+#ifndef LPT_GPU_BVH_LEAF
+#define LPT_GPU_BVH_LEAF 4
+#endif
+constexpr uint32_t kLeafSize = LPT_GPU_BVH_LEAF;
 
 #define LB_HIP(ctx, call)                                                                      \
   do {                                                                                         \
@@ -177,7 +180,10 @@ __global__ void k_copy_flags(const uint32_t* __restrict__ src, uint32_t* __restr
 
 // ---- PLOC ------------------------------------------------------------------------------------
 
-constexpr int kPlocRadius = 16;
+#ifndef LPT_PLOC_RADIUS
+#define LPT_PLOC_RADIUS 16
+#endif
+constexpr int kPlocRadius = LPT_PLOC_RADIUS;
 
 __device__ __forceinline__ float union_area(const float* __restrict__ nodeMin, const float* __restrict__ nodeMax,
                                             uint32_t a, uint32_t b) {
