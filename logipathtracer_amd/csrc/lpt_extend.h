@@ -159,11 +159,16 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         for (;;) {
           float4 q0, q1, q2, q3;
           if (CACHE > 0 && cur < (uint32_t)CACHE) {
-            const float4* q = reinterpret_cast<const float4*>(cache + cur * kCacheStride);
-            q0 = q[0];
-            q1 = q[1];
-            q2 = q[2];
-            q3 = q[3];
+            // volatile LDS reads: kept as ds_read_b128 (left to itself the optimiser merges this branch with the
+            // global one into flat loads on a generic pointer; measured 0 % / -2 % kernel time against those)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef volatile __attribute__((address_space(3))) v4f lds_v4;
+            lds_v4* q = (lds_v4*)(cache + cur * kCacheStride);
+            const v4f a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+            q0 = make_float4(a0.x, a0.y, a0.z, a0.w);
+            q1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+            q2 = make_float4(a2.x, a2.y, a2.z, a2.w);
+            q3 = make_float4(a3.x, a3.y, a3.z, a3.w);
           } else {
             const float4* q = record_words(sc.nodes, cur);
             q0 = q[0];
