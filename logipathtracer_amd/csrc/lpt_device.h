@@ -357,7 +357,10 @@ struct f4 {
 
 __device__ __forceinline__ f4 tex_texel(const DTexture& t, int i, int j) {
   if (i < 0 || j < 0) return f4{0.0f, 0.0f, 0.0f, 1.0f};  // eFloatOpaqueBlack
-  const uint32_t p = reinterpret_cast<const uint32_t*>(t.pixels)[(size_t)j * t.width + (size_t)i];
+  // the pointer comes out of a record in memory, so the compiler cannot tell its address space and would
+  // emit flat loads: texels always live in global memory
+  typedef __attribute__((address_space(1))) const uint32_t global_u32;
+  const uint32_t p = ((global_u32*)t.pixels)[(size_t)j * t.width + (size_t)i];
   return f4{(float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f,
             (float)(p >> 24) / 255.0f};
 }
