@@ -36,15 +36,17 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 }
 
 // PIECES 16-byte loads per record; `active` lanes of each wave take part; QUAD: lanes 4k..4k+3 read the
-// four pieces of the record that lane-group k draws (PIECES must be 4).
-template <int PIECES, bool QUAD>
+// four pieces of the record that lane-group k draws (PIECES must be 4).  SHARE > 1: groups of SHARE
+// neighbouring lanes draw the same record and each reads all of it (lanes of the search that stand at the
+// same node: the L1 then serves one access for the group).
+template <int PIECES, bool QUAD, int SHARE = 1>
 __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ table, uint32_t nRecords, int iters,
                                                 int active, float* __restrict__ out) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.0f;
   if ((int)lane < active) {
-    uint32_t s = mix(QUAD ? (gid >> 2) + 1u : gid + 1u);
+    uint32_t s = mix(QUAD ? (gid >> 2) + 1u : (gid / (uint32_t)SHARE) + 1u);
     constexpr int U = 4;  // independent records in flight per lane
     for (int it = 0; it < iters; it += U) {
       float4 v[U][QUAD ? 1 : PIECES];
@@ -73,6 +75,7 @@ struct Case {
   const char* name;
   int pieces;
   bool quad;
+  int share;
 };
 
 int main() {
@@ -93,7 +96,9 @@ int main() {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  const Case cases[] = {{"lane_64B", 4, false}, {"lane_48B", 3, false}, {"lane_16B", 1, false}, {"quad_64B", 4, true}};
+  const Case cases[] = {{"lane_64B", 4, false, 1},       {"lane_48B", 3, false, 1},       {"lane_16B", 1, false, 1},
+                        {"quad_64B", 4, true, 1},        {"lane_64B_share2", 4, false, 2}, {"lane_64B_share4", 4, false, 4},
+                        {"lane_64B_share8", 4, false, 8}};
   const size_t sizes[] = {16u << 10, 1u << 20, 2u << 20, 16u << 20, 48u << 20};
   const int actives[] = {64, 48, 32, 16};
   for (const Case& c : cases)
@@ -103,6 +108,9 @@ int main() {
         const int iters = 2048;
         auto launch = [&]() {
           if (c.quad) hipLaunchKernelGGL((k_gather<4, true>), dim3(blocks), dim3(256), 0, 0, table, nRec, iters, active, out);
+          else if (c.share == 2) hipLaunchKernelGGL((k_gather<4, false, 2>), dim3(blocks), dim3(256), 0, 0, table, nRec, iters, active, out);
+          else if (c.share == 4) hipLaunchKernelGGL((k_gather<4, false, 4>), dim3(blocks), dim3(256), 0, 0, table, nRec, iters, active, out);
+          else if (c.share == 8) hipLaunchKernelGGL((k_gather<4, false, 8>), dim3(blocks), dim3(256), 0, 0, table, nRec, iters, active, out);
           else if (c.pieces == 4) hipLaunchKernelGGL((k_gather<4, false>), dim3(blocks), dim3(256), 0, 0, table, nRec, iters, active, out);
           else if (c.pieces == 3) hipLaunchKernelGGL((k_gather<3, false>), dim3(blocks), dim3(256), 0, 0, table, nRec, iters, active, out);
           else hipLaunchKernelGGL((k_gather<1, false>), dim3(blocks), dim3(256), 0, 0, table, nRec, iters, active, out);
