@@ -447,3 +447,39 @@ def test_deferred_submission_renders_the_same_image(cornell):
         assert [s for s, _ in got] == [s for s, _ in want] == [7, 3, 7, 4]
         for (_, x), (_, y) in zip(got, want):
             assert x.shape == y.shape and np.array_equal(x, y), n
+
+
+def test_caller_owned_stream(cornell, cornell_oracle):
+    """lpt_set_stream: the work runs on a stream the caller owns (here a torch stream), ordered with the caller's
+    own work on it; NULL gives the context its stream back."""
+    torch = pytest.importorskip("torch")
+    w, h, bounces = 160, 96, 4
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, 3, seed=17)
+    ref, st = O.render_frames(cornell_oracle, ubos, w, h, bounces)
+    dev = L.Device(0)
+    try:
+        dev.upload_scene(cornell)
+        dev.resize(w, h)
+        dev.set_options(bounces, L.BSDF_HEITZ, L.PIPELINE_AUTO, 0)
+        stream = torch.cuda.Stream(device=0)
+        dev.set_stream(stream.cuda_stream)
+        dev.render_frames(ubos[:2])
+        # the compact buffer is read by torch on the same stream: ordered behind the render without a host sync
+        n_floats = dev.owned_slots() * 4
+
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (dev.owned_accum_device(), False), "version": 3}
+
+        with torch.cuda.stream(stream):
+            alpha_sum = torch.as_tensor(_Arr(), device="cuda:0").view(-1, 4)[:, 3].sum()
+        stream.synchronize()
+        assert float(alpha_sum) == 2.0 * w * h
+        dev.render_frame_static(ubos[2:3])   # the entry point that allocates nothing uses the same stream
+        stream.synchronize()
+        assert np.array_equal(dev.read_accum(), ref)
+        dev.set_stream(None)
+        dev.resize(w, h)
+        dev.render_frames(ubos)
+        assert np.array_equal(dev.read_accum(), ref) and dev.stats().segments == st["segments"]
+    finally:
+        dev.close()
