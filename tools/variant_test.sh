@@ -19,8 +19,8 @@ for spec in "$@"; do
 done
 wait
 for n in "${names[@]}"; do if [ ! -f $V/$n.so ]; then echo "build of $n failed"; cat $V/$n.err | head -20; exit 1; fi; done
-cmd="true"
+cmd="mkdir -p gpurun_out"
 for n in "${names[@]}"; do
-  cmd="$cmd; cp $V/$n.so logipathtracer_amd/lib/liblpt_hip.so; echo '== $n'; timeout -k 10 300 python -m pytest tests/test_gpu_parity.py tests/test_synthetic_scenes.py -m gpu -x -q --timeout 200 --timeout-method thread 2>&1 | tail -1; echo -n 'cornell: '; timeout -k 10 120 bash tools/bench_pipe.sh $P; echo -n 'outside: '; timeout -k 10 120 bash tools/bench_pipe.sh $P --scene outside_synth --spp-per-step 32"
+  cmd="$cmd && cp $V/$n.so logipathtracer_amd/lib/liblpt_hip.so && echo '== $n' && timeout -k 10 300 python -m pytest tests/test_gpu_parity.py tests/test_synthetic_scenes.py -m gpu -x -q --timeout 200 --timeout-method thread 2>&1 | tail -1 && echo -n 'cornell: ' && timeout -k 10 120 bash tools/bench_pipe.sh $P && echo -n 'outside: ' && timeout -k 10 120 bash tools/bench_pipe.sh $P --scene outside_synth --spp-per-step 32"
 done
 /usr/local/graft/bin/gpurun --timeout 1100 -- "$cmd" 2>&1 | grep -vE "^\[gpurun\] (sending|merged)"
