@@ -31,8 +31,10 @@
 namespace lpt {
 
 #ifdef LPT_EXTEND_STATS
-// analysis aid: [2k] rounds (or burst iterations) of kind k, [2k+1] lanes that took part
-__device__ unsigned long long g_extendStats[16];
+// analysis aid: [2k] rounds (or burst iterations) of kind k, [2k+1] lanes that took part (k < 6);
+// [12] longest time a wave went on after the queue ran dry, [14] sum of those times, [15] sum of all wave
+// times (100 MHz ticks); [16 + k] rays that took 32k .. 32k+31 steps (the counting slows the kernel down)
+__device__ unsigned long long g_extendStats[16 + 64];
 #define LPT_XSTAT(k, lanes) (++xsR[k], xsL[k] += (uint32_t)(lanes))
 #else
 #define LPT_XSTAT(k, lanes) ((void)0)
@@ -97,7 +99,12 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
   int sp = 0;
 
 #ifdef LPT_EXTEND_STATS
-  uint32_t xsR[8] = {}, xsL[8] = {};
+  uint32_t xsR[8] = {}, xsL[8] = {}, xsSteps = 0;
+  const unsigned long long xsT0 = wall_clock64();
+  unsigned long long xsTx = 0;
+#define LPT_XSTEP() (++xsSteps)
+#else
+#define LPT_XSTEP() ((void)0)
 #endif
   for (;;) {
     const unsigned long long bF = __ballot(state == kStFetch);
@@ -107,6 +114,9 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     const int nF = __popcll(bF), nI = __popcll(bI), nT = __popcll(bT), nO = __popcll(bO);
     const int busy = nI + nT + nO;
     if (busy + nF == 0) break;
+#ifdef LPT_EXTEND_STATS
+    if (exhausted && !xsTx) xsTx = wall_clock64();
+#endif
 
     bool stepped = false;  // this lane advanced and holds a new `cur` (or needs a pop)
     bool needPop = false;
@@ -178,6 +188,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
           }
           bool h0, h1;
           box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
+          LPT_XSTEP();
           const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
           if (h0 && h1) stk[(sp++) * BLOCK] = r0;
           cur = h1 ? r1 : r0;
@@ -204,6 +215,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
               hit.obj = curObj;
               hit.prim = as_uint(a.w);
             }
+            LPT_XSTEP();
             if (++triI >= triEnd) break;  // leaf done: this lane leaves the burst
             const int left = __popcll(__ballot(1));
             if (it >= kBurstTriFree && LPT_BURST_TRI_DEN * left < LPT_BURST_TRI_NUM * nT) break;
@@ -251,6 +263,10 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         cur = stk[(--sp) * BLOCK];
       }
       if (cur == kRefSentinel) {
+#ifdef LPT_EXTEND_STATS
+        atomicAdd(&g_extendStats[16 + min(xsSteps >> 5, 63u)], 1ull);
+        xsSteps = 0;
+#endif
         hits[rayIdx] = make_float4(hit.t, as_float(hit.obj), as_float(hit.prim), 0.0f);
         state = kStFetch;
       } else if (!(cur & kRefLeafBit)) {
@@ -265,11 +281,16 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     }
   }
 #ifdef LPT_EXTEND_STATS
-  if (lane == 0)
+  if (lane == 0) {
     for (int k = 0; k < 6; ++k) {
       atomicAdd(&g_extendStats[2 * k], (unsigned long long)xsR[k]);
       atomicAdd(&g_extendStats[2 * k + 1], (unsigned long long)xsL[k]);
     }
+    const unsigned long long t1 = wall_clock64();
+    atomicMax(&g_extendStats[12], t1 - (xsTx ? xsTx : t1));
+    atomicAdd(&g_extendStats[14], t1 - (xsTx ? xsTx : t1));
+    atomicAdd(&g_extendStats[15], t1 - xsT0);
+  }
 #endif
 }
 

@@ -1732,12 +1732,17 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   LPT_HIP(c, hipMemcpy(totals, c->dTotals, sizeof totals, hipMemcpyDeviceToHost));
 #ifdef LPT_EXTEND_STATS
   {
-    unsigned long long t[16];
+    unsigned long long t[16 + 64];
     LPT_HIP(c, hipMemcpyFromSymbol(t, HIP_SYMBOL(lpt::g_extendStats), sizeof t));
     const char* names[6] = {"fetch", "inner", "tri", "obj", "inner+", "tri+"};
     for (int k = 0; k < 6; ++k)
       std::fprintf(stderr, "extend rounds %-7s %12llu  lanes/round %.1f\n", names[k], t[2 * k],
                    t[2 * k] ? (double)t[2 * k + 1] / (double)t[2 * k] : 0.0);
+    std::fprintf(stderr, "extend waves after the queue ran dry: %.2f %% of all wave time, longest %.3f ms\n",
+                 t[15] ? 100.0 * (double)t[14] / (double)t[15] : 0.0, (double)t[12] * 1e-5);
+    std::fprintf(stderr, "extend rays by steps (bins of 32):");
+    for (int k = 0; k < 64 && t[16 + k]; ++k) std::fprintf(stderr, " %llu", t[16 + k]);
+    std::fprintf(stderr, "\n");
   }
 #endif
 #ifdef LPT_TRACE_STATS
