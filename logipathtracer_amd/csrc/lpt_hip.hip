@@ -1,9 +1,12 @@
 // HIP kernels and C-ABI of the MI355X device layer (see include/lpt.h).
 //
-// Two kernel organisations render identical pixels:
-//  * wavefront: Structure-of-Arrays path queues in HBM; per bounce one traversal
-//    kernel (k_extend, node stack in LDS) and one shading kernel (k_shade) that
-//    compacts surviving paths into the next queue with a wave ballot;
+// Four kernel organisations render identical pixels:
+//  * wavefront: Structure-of-Arrays path queues in HBM; the first segment of every path in one packet
+//    kernel (k_primary_shade), then per bounce one traversal kernel (k_extend, node stack in LDS) and one
+//    shading kernel (k_shade) that compacts surviving paths into the next queue with a wave ballot; the
+//    thinned-out late bounces in one queue-fed persistent launch (k_trace);
+//  * hybrid: the first segment as above, everything after it in one queue-fed k_trace launch;
+//  * persistent: one k_trace launch per batch, paths stay in a lane from ray generation to their radiance;
 //  * megakernel: one thread per pixel runs the whole path (the organisation of
 //    shaders/path_tracing.comp::main).
 //
@@ -1554,6 +1557,10 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
 
   free_scene(c);
   float* dBase = nullptr;
+  struct Cleanup {  // the staging buffer goes on every path out of this function
+    float*& p;
+    ~Cleanup() { (void)hipFree(p); }
+  } cleanup{dBase};
   LPT_HIP(c, hipMalloc(&c->dNodes, nodes.size() * sizeof(TNode)));
   LPT_HIP(c, hipMalloc(&c->dTris, std::max<size_t>(1, tris.size()) * sizeof(Tri)));
   LPT_HIP(c, hipMalloc(&c->dObjTrav, otrav.size() * sizeof(ObjTrav)));
@@ -1569,7 +1576,6 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
   hipLaunchKernelGGL(k_finish_objects, dim3((nObj + 63) / 64), dim3(64), 0, c->stream, c->dObjShade, dBase, nObj);
   LPT_HIP(c, hipGetLastError());
   LPT_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(dBase);
   c->rootRef = sceneRoot;
   c->nNodes = (uint32_t)order.size();
   c->nTris = (uint32_t)tris.size();

@@ -476,6 +476,7 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
   while (!st.empty()) {
     Item it = st.back();
     st.pop_back();
+    if (count >= nNodes) return lpt_internal_fail(ctx, LPT_ERR_INVALID, "GPU BVH build produced a malformed tree");
     uint32_t slot = count++;
     lpt_bvh_node& g = nodesOut[slot];
     std::memset(&g, 0, sizeof g);
@@ -489,6 +490,7 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
         const uint32_t v = gather.back();
         gather.pop_back();
         if (v >= nInternal) {
+          if (placed >= n) return lpt_internal_fail(ctx, LPT_ERR_INVALID, "GPU BVH build produced a malformed tree");
           primOrderOut[placed++] = sorted[v - nInternal];
         } else {
           gather.push_back(right[v]);
