@@ -14,7 +14,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(HIPFLAGS_EXTRA) -ffp-c
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra
 
-HOST_SRCS := $(HOST)/lsg_min.cpp $(HOST)/png_decode.cpp $(HOST)/lsg_bvh.cpp $(HOST)/pt_scene_converter.cpp \
+HOST_SRCS := $(HOST)/lsg_min.cpp $(HOST)/png_decode.cpp $(HOST)/jpeg_decode.cpp $(HOST)/lsg_bvh.cpp $(HOST)/pt_scene_converter.cpp \
              $(HOST)/renderer_core.cpp $(HOST)/renderer_pt.cpp $(HOST)/host_capi.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/lpt.h
 DEV_HDRS  := $(wildcard $(CSRC)/*.h) include/lpt.h

@@ -1,4 +1,5 @@
 #include "lsg_min.hpp"
+#include "jpeg_decode.hpp"
 #include "png_decode.hpp"
 
 #include <cstring>
@@ -265,9 +266,13 @@ Ref<Image> loadImage(Doc& d, size_t index) {
   } else {
     throw std::runtime_error("glTF: image without uri or bufferView");
   }
-  if (bytes.size() >= 3 && (unsigned char)bytes[0] == 0xFF && (unsigned char)bytes[1] == 0xD8)
-    throw std::runtime_error("glTF: JPEG texture images are not supported (convert '" + img->uri + "' to PNG)");
-  decodePNG(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), img->pixels_, img->width_, img->height_);
+  const uint8_t* raw = reinterpret_cast<const uint8_t*>(bytes.data());
+  try {
+    if (bytes.size() >= 3 && raw[0] == 0xFF && raw[1] == 0xD8) decodeJPEG(raw, bytes.size(), img->pixels_, img->width_, img->height_);
+    else decodePNG(raw, bytes.size(), img->pixels_, img->width_, img->height_);
+  } catch (const std::runtime_error& e) {
+    throw std::runtime_error("glTF: image " + std::to_string(index) + " ('" + img->uri + "'): " + e.what());
+  }
   d.images[index] = img;
   return img;
 }

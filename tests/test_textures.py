@@ -1,6 +1,6 @@
 """Textured materials (the five texture slots of shaders/path_tracing.comp:244-261,277-282).
 
-CPU: the PNG reader of the glTF loader against PIL, the oracle's texture fetch against hand-derived
+CPU: the PNG and JPEG readers of the glTF loader against PIL / libjpeg pixels, the oracle's texture fetch against hand-derived
 values, the sampler hand-over of the scene converter (including the reference's use of wrappingW for the
 V axis).  GPU: parity of a scene that uses every slot, filter and wrap mode with the oracle.  Linear
 filtering follows the fixed formula of the arithmetic contract; a Vulkan device's own filtering is not
@@ -62,17 +62,58 @@ def test_png_reader_matches_pil_for_all_filters_and_colour_types(textured, tmp_p
         assert np.array_equal(s.textures[0]["pixels"], ref), name
 
 
-def test_jpeg_and_missing_images_are_rejected_with_a_message(tmp_path):
+def _one_texture_scene(tmp_path, image_name):
+    """A quad whose base colour texture is `image_name` (a file in tmp_path); returns the loaded scene."""
     g = scenes._GltfBuilder()
-    m = g.material("M", base_tex=g.texture("photo.jpg"))
+    m = g.material("M", base_tex=g.texture(image_name))
     quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
     g.node("Q", mesh=g.mesh("Q", [(quad, quad * 0 + [0, 1, 0], np.array([0, 2, 1, 0, 3, 2], np.uint32), m)]))
-    g.write(str(tmp_path / "j.gltf"))
+    path = str(tmp_path / (image_name + ".gltf"))
+    g.write(path)
+    return L.Scene(path)
+
+
+def test_missing_and_damaged_images_are_rejected_with_a_message(tmp_path):
     with pytest.raises(L.LptError, match="failed to open"):
-        L.Scene(str(tmp_path / "j.gltf"))
+        _one_texture_scene(tmp_path, "photo.jpg")
     open(str(tmp_path / "photo.jpg"), "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 32)
     with pytest.raises(L.LptError, match="JPEG"):
-        L.Scene(str(tmp_path / "j.gltf"))
+        _one_texture_scene(tmp_path, "photo.jpg")
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["jpeg_444", "jpeg_422", "jpeg_420_restart", "jpeg_grey", "jpeg_optimized"])
+def test_jpeg_reader_against_libjpeg_pixels(tmp_path, name):
+    """Baseline JPEG files written by Pillow (tests/golden/make_jpeg_fixtures.py) and the pixels Pillow decodes
+    from them.  JPEG allows a decoder a level or two per sample (inverse DCT, chroma interpolation), so the
+    comparison is not bit-exact: every sample within 3 levels, mean difference below half a level."""
+    import shutil
+    shutil.copy(os.path.join(GOLDEN, name + ".jpg"), str(tmp_path / (name + ".jpg")))
+    scene = _one_texture_scene(tmp_path, name + ".jpg")
+    got = scene.textures[0]["pixels"].astype(np.int32)
+    ref = np.load(os.path.join(GOLDEN, "jpeg_expected.npz"))[name].astype(np.int32)
+    assert got.shape == ref.shape
+    assert np.array_equal(got[..., 3], ref[..., 3])
+    diff = np.abs(got - ref)
+    assert diff.max() <= 3, diff.max()
+    assert diff.mean() < 0.5, diff.mean()
+
+
+def test_progressive_jpeg_is_refused_by_name(tmp_path):
+    import shutil
+    shutil.copy(os.path.join(GOLDEN, "jpeg_progressive.jpg"), str(tmp_path / "p.jpg"))
+    with pytest.raises(L.LptError, match="progressive JPEG is not supported"):
+        _one_texture_scene(tmp_path, "p.jpg")
+
+
+def test_truncated_jpeg_fails_cleanly(tmp_path):
+    data = open(os.path.join(GOLDEN, "jpeg_420_restart.jpg"), "rb").read()
+    for cut in (len(data) // 3, len(data) - 40, 30):
+        open(str(tmp_path / "t.jpg"), "wb").write(data[:cut])
+        with pytest.raises(L.LptError, match="JPEG"):
+            _one_texture_scene(tmp_path, "t.jpg")
 
 
 def test_texture_fetch_known_answers():
