@@ -114,6 +114,7 @@ struct Component {
   int planeW = 0, planeH = 0;  // whole MCUs
   int compW = 0, compH = 0;    // samples that belong to the image
   std::vector<uint8_t> plane;
+  std::vector<int> coefs;  // progressive frames: 64 coefficients per block of the plane, natural order, not yet dequantised
   int pred = 0;
   int td = 0, ta = 0;
   bool decoded = false;
@@ -159,7 +160,7 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
   int X = 0, Y = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
   int restartInterval = 0;
   int adobeTransform = -1;
-  bool haveFrame = false, ended = false;
+  bool haveFrame = false, ended = false, progressive = false;
 
   size_t pos = 2;
   while (!ended) {
@@ -206,8 +207,9 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
         (tc ? ac[th] : dc[th]).build(seg + o + 1, seg + o + 17, total);
         o += 17 + (size_t)total;
       }
-    } else if (marker == 0xC0 || marker == 0xC1) {  // frame header, sequential DCT with Huffman coding
+    } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {  // frame header, Huffman-coded DCT
       if (haveFrame) bad("more than one frame");
+      progressive = marker == 0xC2;
       if (segLen < 6) bad("truncated frame header");
       if (seg[0] != 8) bad("only 8 bits per sample are supported");
       Y = (seg[1] << 8) | seg[2];
@@ -237,10 +239,9 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
         c.compW = (X * c.h + hmax - 1) / hmax;
         c.compH = (Y * c.v + vmax - 1) / vmax;
         c.plane.assign((size_t)c.planeW * c.planeH, 128);
+        if (progressive) c.coefs.assign((size_t)c.planeW * c.planeH, 0);
       }
       haveFrame = true;
-    } else if (marker == 0xC2) {
-      bad("progressive JPEG is not supported (save the image as baseline JPEG or PNG)");
     } else if ((marker >= 0xC3 && marker <= 0xCF) && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {
       bad("lossless, hierarchical and arithmetic-coded JPEG are not supported");
     } else if (marker == 0xCC) {
@@ -262,17 +263,27 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
         for (Component& c : comps)
           if (c.id == cs) found = &c;
         if (!found) bad("scan names an unknown component");
-        if (found->decoded) bad("component coded twice");
+        if (!progressive && found->decoded) bad("component coded twice");
         found->td = seg[2 + 2 * i] >> 4;
         found->ta = seg[2 + 2 * i] & 15;
-        if (found->td > 3 || found->ta > 3 || !dc[found->td].present || !ac[found->ta].present)
-          bad("scan uses a Huffman table that was not defined");
+        if (found->td > 3 || found->ta > 3) bad("bad Huffman table selector");
         if (!haveQuant[found->tq]) bad("component uses a quantisation table that was not defined");
         found->pred = 0;
         sc.push_back(found);
       }
-      const int ss = seg[1 + 2 * ns], se = seg[2 + 2 * ns], ahal = seg[3 + 2 * ns];
-      if (ss != 0 || se != 63 || ahal != 0) bad("scan parameters of a progressive file in a sequential frame");
+      const int ss = seg[1 + 2 * ns], se = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+      if (!progressive) {
+        if (ss != 0 || se != 63 || ah != 0 || al != 0) bad("scan parameters of a progressive file in a sequential frame");
+      } else {
+        if (ss > se || se > 63 || al > 13 || (ah != 0 && ah != al + 1)) bad("bad progressive scan parameters");
+        if (ss == 0 && se != 0) bad("progressive scan mixes DC and AC coefficients");
+        if (ss > 0 && ns != 1) bad("progressive AC scan with more than one component");
+      }
+      for (Component* c : sc) {  // the tables this kind of scan decodes with
+        const bool needDc = !progressive || (ss == 0 && ah == 0), needAc = !progressive || ss > 0;
+        if ((needDc && !dc[c->td].present) || (needAc && !ac[c->ta].present))
+          bad("scan uses a Huffman table that was not defined");
+      }
 
       BitReader br{data + pos, data + size};
       int coef[64];
@@ -299,6 +310,98 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
         }
         idct.run(coef, &c.plane[(size_t)by * 8 * c.planeW + (size_t)bx * 8], c.planeW);
       };
+      // Progressive scans (ITU-T T.81 annex G) add to the stored coefficients of a block: a band ss..se of the
+      // zigzag order, either its first `8 - al` high bits (ah == 0) or one more bit of precision (ah > 0).
+      int eobrun = 0;  // blocks still covered by the last end-of-band run
+      auto progressiveBlock = [&](Component& c, int bx, int by) {
+        int* cf = &c.coefs[((size_t)by * (c.planeW / 8) + (size_t)bx) * 64];
+        const int p1 = 1 << al, m1 = -(1 << al);
+        auto refine = [&](int& v) {  // one more bit for a coefficient that is already non-zero
+          if (br.bit() && (v & p1) == 0) v += v >= 0 ? p1 : m1;
+        };
+        if (ss == 0) {
+          if (ah == 0) {
+            const int t = br.decode(dc[c.td]);
+            if (t > 11) bad("DC difference of more than 11 bits");
+            c.pred += t ? extend(br.bits(t), t) : 0;
+            if (c.pred < -32767 || c.pred > 32767) bad("DC value out of range");
+            cf[0] = c.pred * (1 << al);
+          } else if (br.bit()) {
+            cf[0] |= p1;
+          }
+          return;
+        }
+        int k = ss;
+        if (ah == 0) {
+          if (eobrun > 0) {
+            --eobrun;
+            return;
+          }
+          while (k <= se) {
+            const int rs = br.decode(ac[c.ta]);
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+              if (r < 15) {  // end of band for this block and 2^r - 1 + (r more bits) blocks after it
+                eobrun = (1 << r) - 1;
+                if (r) eobrun += br.bits(r);
+                break;
+              }
+              k += 16;
+              continue;
+            }
+            k += r;
+            if (k > se) bad("coefficient index beyond the band");
+            cf[kZigzag[k]] = extend(br.bits(sz), sz) * (1 << al);
+            ++k;
+          }
+          return;
+        }
+        if (eobrun == 0) {
+          while (k <= se) {
+            const int rs = br.decode(ac[c.ta]);
+            int r = rs >> 4;
+            const int sz = rs & 15;
+            int value = 0;
+            if (sz == 0) {
+              if (r < 15) {
+                eobrun = 1 << r;
+                if (r) eobrun += br.bits(r);
+                break;
+              }
+            } else {
+              if (sz != 1) bad("refinement scan with a coefficient of more than one bit");
+              value = br.bit() ? p1 : m1;
+            }
+            // pass over coefficients that are already non-zero (each takes a correction bit) and over r zeros
+            while (k <= se) {
+              int& v = cf[kZigzag[k]];
+              if (v != 0) {
+                refine(v);
+              } else {
+                if (r == 0) break;
+                --r;
+              }
+              ++k;
+            }
+            if (value != 0) {
+              if (k > se) bad("coefficient index beyond the band");
+              cf[kZigzag[k]] = value;
+            }
+            ++k;
+          }
+        }
+        if (eobrun > 0) {  // the rest of the band holds no new coefficients: correction bits only
+          for (; k <= se; ++k) {
+            int& v = cf[kZigzag[k]];
+            if (v != 0) refine(v);
+          }
+          --eobrun;
+        }
+      };
+      auto codedBlock = [&](Component& c, int bx, int by) {
+        if (progressive) progressiveBlock(c, bx, by);
+        else block(c, bx, by);
+      };
       long long units, done = 0;
       int nextRst = 0;
       auto maybeRestart = [&]() {
@@ -306,6 +409,7 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
         if (restartInterval && done % restartInterval == 0 && done < units) {
           br.restart(nextRst);
           nextRst = (nextRst + 1) & 7;
+          eobrun = 0;
           for (Component* c : sc) c->pred = 0;
         }
       };
@@ -315,7 +419,7 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
         units = (long long)bw * bh;
         for (int by = 0; by < bh; ++by)
           for (int bx = 0; bx < bw; ++bx) {
-            block(c, bx, by);
+            codedBlock(c, bx, by);
             maybeRestart();
           }
       } else {
@@ -324,7 +428,7 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
           for (int mx = 0; mx < mcux; ++mx) {
             for (Component* c : sc)
               for (int v = 0; v < c->v; ++v)
-                for (int h = 0; h < c->h; ++h) block(*c, mx * c->h + h, my * c->v + v);
+                for (int h = 0; h < c->h; ++h) codedBlock(*c, mx * c->h + h, my * c->v + v);
             maybeRestart();
           }
       }
@@ -337,6 +441,24 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
   if (!haveFrame) bad("no frame header");
   for (const Component& c : comps)
     if (!c.decoded) bad("a component has no scan");
+  if (progressive) {
+    for (Component& c : comps) {
+      const uint16_t* q = quant[c.tq];
+      int natural[64];  // the table in natural order
+      for (int k = 0; k < 64; ++k) natural[kZigzag[k]] = q[k];
+      const int bw = c.planeW / 8, bh = c.planeH / 8;
+      int coef[64];
+      for (int by = 0; by < bh; ++by)
+        for (int bx = 0; bx < bw; ++bx) {
+          const int* cf = &c.coefs[((size_t)by * bw + (size_t)bx) * 64];
+          for (int k = 0; k < 64; ++k) {
+            const int v = cf[k] < -32767 ? -32767 : (cf[k] > 32767 ? 32767 : cf[k]);  // (only damaged files exceed this)
+            coef[k] = v * natural[k];
+          }
+          idct.run(coef, &c.plane[(size_t)by * 8 * c.planeW + (size_t)bx * 8], c.planeW);
+        }
+    }
+  }
 
   // full-resolution sample of component c at pixel (x, y)
   auto sample = [&](const Component& c, int x, int y) -> int {

@@ -1,7 +1,7 @@
-// JPEG reader for glTF texture images: Huffman-coded sequential DCT (baseline and extended sequential,
-// SOF0 / SOF1) at 8 bits per sample, one component (grey) or three (YCbCr, or RGB when an Adobe marker
-// says so), any sampling factors, interleaved and non-interleaved scans, restart intervals.  Progressive,
-// arithmetic-coded, lossless, 12-bit and four-component files are refused by name.  Output is RGBA8.
+// JPEG reader for glTF texture images: Huffman-coded DCT frames, sequential (baseline and extended, SOF0 /
+// SOF1) and progressive (SOF2), at 8 bits per sample, one component (grey) or three (YCbCr, or RGB when an
+// Adobe marker says so), any sampling factors, interleaved and non-interleaved scans, restart intervals.
+// Arithmetic-coded, lossless, hierarchical, 12-bit and four-component files are refused by name.  Output is RGBA8.
 //
 // JPEG leaves the inverse DCT and the chroma interpolation to the decoder within an error bound, so two
 // decoders differ by a level or two per sample; the rules used here are fixed (see jpeg_decode.cpp) so

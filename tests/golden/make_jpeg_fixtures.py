@@ -30,6 +30,10 @@ def main():
         "jpeg_grey": dict(size=(33, 18), mode="L", kw=dict(quality=88)),
         "jpeg_optimized": dict(size=(40, 40), mode="RGB", kw=dict(quality=75, subsampling=2, optimize=True)),
         "jpeg_progressive": dict(size=(24, 24), mode="RGB", kw=dict(quality=80, progressive=True)),
+        "jpeg_progressive_444": dict(size=(45, 31), mode="RGB", kw=dict(quality=93, progressive=True, subsampling=0,
+                                                                        restart_marker_blocks=4)),
+        "jpeg_progressive_grey": dict(size=(19, 26), mode="L", kw=dict(quality=70, progressive=True, optimize=True)),
+        "jpeg_cmyk": dict(size=(16, 16), mode="CMYK", kw=dict(quality=80)),
     }
     expected = {}
     for i, (name, c) in enumerate(cases.items()):

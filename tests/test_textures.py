@@ -84,9 +84,10 @@ def test_missing_and_damaged_images_are_rejected_with_a_message(tmp_path):
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", ["jpeg_444", "jpeg_422", "jpeg_420_restart", "jpeg_grey", "jpeg_optimized"])
+@pytest.mark.parametrize("name", ["jpeg_444", "jpeg_422", "jpeg_420_restart", "jpeg_grey", "jpeg_optimized",
+                                  "jpeg_progressive", "jpeg_progressive_444", "jpeg_progressive_grey"])
 def test_jpeg_reader_against_libjpeg_pixels(tmp_path, name):
-    """Baseline JPEG files written by Pillow (tests/golden/make_jpeg_fixtures.py) and the pixels Pillow decodes
+    """Baseline and progressive JPEG files written by Pillow (tests/golden/make_jpeg_fixtures.py) and the pixels Pillow decodes
     from them.  JPEG allows a decoder a level or two per sample (inverse DCT, chroma interpolation), so the
     comparison is not bit-exact: every sample within 3 levels, mean difference below half a level."""
     import shutil
@@ -101,19 +102,20 @@ def test_jpeg_reader_against_libjpeg_pixels(tmp_path, name):
     assert diff.mean() < 0.5, diff.mean()
 
 
-def test_progressive_jpeg_is_refused_by_name(tmp_path):
+def test_four_component_jpeg_is_refused_by_name(tmp_path):
     import shutil
-    shutil.copy(os.path.join(GOLDEN, "jpeg_progressive.jpg"), str(tmp_path / "p.jpg"))
-    with pytest.raises(L.LptError, match="progressive JPEG is not supported"):
-        _one_texture_scene(tmp_path, "p.jpg")
+    shutil.copy(os.path.join(GOLDEN, "jpeg_cmyk.jpg"), str(tmp_path / "c.jpg"))
+    with pytest.raises(L.LptError, match="four-component"):
+        _one_texture_scene(tmp_path, "c.jpg")
 
 
 def test_truncated_jpeg_fails_cleanly(tmp_path):
-    data = open(os.path.join(GOLDEN, "jpeg_420_restart.jpg"), "rb").read()
-    for cut in (len(data) // 3, len(data) - 40, 30):
-        open(str(tmp_path / "t.jpg"), "wb").write(data[:cut])
-        with pytest.raises(L.LptError, match="JPEG"):
-            _one_texture_scene(tmp_path, "t.jpg")
+    for name in ("jpeg_420_restart.jpg", "jpeg_progressive_444.jpg"):
+        data = open(os.path.join(GOLDEN, name), "rb").read()
+        for cut in (len(data) // 3, len(data) - 40, 30):
+            open(str(tmp_path / "t.jpg"), "wb").write(data[:cut])
+            with pytest.raises(L.LptError, match="JPEG"):
+                _one_texture_scene(tmp_path, "t.jpg")
 
 
 def test_texture_fetch_known_answers():
