@@ -27,6 +27,7 @@ void decodePNG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, uin
   bool haveHeader = false;
   uint32_t w = 0, h = 0;
   int depth = 0, colorType = 0;
+  bool interlaced = false;
   std::vector<uint8_t> idat, palette, trns;
   bool ended = false;
   while (!ended && pos + 12 <= size) {
@@ -41,7 +42,8 @@ void decodePNG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, uin
       depth = body[8];
       colorType = body[9];
       if (body[10] != 0 || body[11] != 0) throw std::runtime_error("PNG: unknown compression or filter method");
-      if (body[12] != 0) throw std::runtime_error("PNG: interlaced images are not supported");
+      if (body[12] > 1) throw std::runtime_error("PNG: unknown interlace method");
+      interlaced = body[12] == 1;
       haveHeader = true;
     } else if (std::memcmp(type, "PLTE", 4) == 0) {
       palette.assign(body, body + len);
@@ -73,8 +75,24 @@ void decodePNG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, uin
 
   const size_t bitsPerPixel = (size_t)channels * (size_t)depth;
   const size_t bpp = (bitsPerPixel + 7) / 8;  // filter distance in bytes
-  const size_t rowBytes = ((size_t)w * bitsPerPixel + 7) / 8;
-  std::vector<uint8_t> raw((rowBytes + 1) * (size_t)h);
+  // The image as a sequence of passes: one for a plain file, seven reduced images for an interlaced one
+  // (Adam7: pass p holds the pixels x0 + i*dx, y0 + j*dy).  Every pass is a run of filtered scan lines of its own.
+  struct Pass { uint32_t x0, y0, dx, dy, w, h; size_t rowBytes; };
+  std::vector<Pass> passes;
+  if (!interlaced) {
+    passes.push_back(Pass{0, 0, 1, 1, w, h, ((size_t)w * bitsPerPixel + 7) / 8});
+  } else {
+    static const uint32_t X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1};
+    static const uint32_t DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+    for (int p = 0; p < 7; ++p) {
+      const uint32_t pw = w > X0[p] ? (w - X0[p] + DX[p] - 1) / DX[p] : 0u;
+      const uint32_t ph = h > Y0[p] ? (h - Y0[p] + DY[p] - 1) / DY[p] : 0u;
+      if (pw && ph) passes.push_back(Pass{X0[p], Y0[p], DX[p], DY[p], pw, ph, ((size_t)pw * bitsPerPixel + 7) / 8});
+    }
+  }
+  size_t rawBytes = 0;
+  for (const Pass& ps : passes) rawBytes += (ps.rowBytes + 1) * (size_t)ps.h;
+  std::vector<uint8_t> raw(rawBytes);
   z_stream zs;
   std::memset(&zs, 0, sizeof zs);
   if (inflateInit(&zs) != Z_OK) throw std::runtime_error("PNG: inflateInit failed");
@@ -88,64 +106,68 @@ void decodePNG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, uin
   if ((zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR) || produced != raw.size())
     throw std::runtime_error("PNG: compressed data is damaged or has the wrong length");
 
-  // undo the scan-line filters in place
-  std::vector<uint8_t> zeroRow(rowBytes, 0);
-  for (uint32_t y = 0; y < h; ++y) {
-    uint8_t* line = raw.data() + (rowBytes + 1) * (size_t)y;
-    const int filter = line[0];
-    uint8_t* cur = line + 1;
-    const uint8_t* up = y ? line - rowBytes : zeroRow.data();
-    for (size_t i = 0; i < rowBytes; ++i) {
-      const int a = i >= bpp ? cur[i - bpp] : 0;
-      const int b = up[i];
-      const int c = i >= bpp ? up[i - bpp] : 0;
-      int v = cur[i];
-      switch (filter) {
-        case 0: break;
-        case 1: v += a; break;
-        case 2: v += b; break;
-        case 3: v += (a + b) >> 1; break;
-        case 4: v += paeth(a, b, c); break;
-        default: throw std::runtime_error("PNG: unknown scan-line filter");
-      }
-      cur[i] = (uint8_t)v;
-    }
-  }
-
   rgba.assign((size_t)w * h * 4, 255);
   const int maxv = (1 << (depth > 8 ? 8 : depth)) - 1;
-  for (uint32_t y = 0; y < h; ++y) {
-    const uint8_t* cur = raw.data() + (rowBytes + 1) * (size_t)y + 1;
-    for (uint32_t x = 0; x < w; ++x) {
-      int s[4] = {0, 0, 0, 0};  // samples reduced to 8 bits (16-bit: high byte)
-      for (int k = 0; k < channels; ++k) {
-        const size_t idx = (size_t)x * channels + k;
-        if (depth == 16) s[k] = cur[idx * 2];
-        else if (depth == 8) s[k] = cur[idx];
-        else {
-          const size_t bit = idx * (size_t)depth;
-          s[k] = (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & maxv;
+  size_t passStart = 0;
+  for (const Pass& ps : passes) {
+    const size_t rowBytes = ps.rowBytes;
+    // undo the scan-line filters in place (the line above the first one of a pass counts as zeros)
+    std::vector<uint8_t> zeroRow(rowBytes, 0);
+    for (uint32_t y = 0; y < ps.h; ++y) {
+      uint8_t* line = raw.data() + passStart + (rowBytes + 1) * (size_t)y;
+      const int filter = line[0];
+      uint8_t* cur = line + 1;
+      const uint8_t* up = y ? line - rowBytes : zeroRow.data();
+      for (size_t i = 0; i < rowBytes; ++i) {
+        const int a = i >= bpp ? cur[i - bpp] : 0;
+        const int b = up[i];
+        const int c = i >= bpp ? up[i - bpp] : 0;
+        int v = cur[i];
+        switch (filter) {
+          case 0: break;
+          case 1: v += a; break;
+          case 2: v += b; break;
+          case 3: v += (a + b) >> 1; break;
+          case 4: v += paeth(a, b, c); break;
+          default: throw std::runtime_error("PNG: unknown scan-line filter");
         }
-      }
-      uint8_t* o = &rgba[((size_t)y * w + x) * 4];
-      switch (colorType) {
-        case 0: {
-          const int g = depth < 8 ? s[0] * 255 / maxv : s[0];
-          o[0] = o[1] = o[2] = (uint8_t)g;
-          break;
-        }
-        case 2: o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; break;
-        case 3: {
-          const size_t pi = (size_t)s[0];
-          if (pi * 3 + 2 >= palette.size()) throw std::runtime_error("PNG: palette index out of range");
-          o[0] = palette[pi * 3]; o[1] = palette[pi * 3 + 1]; o[2] = palette[pi * 3 + 2];
-          if (pi < trns.size()) o[3] = trns[pi];
-          break;
-        }
-        case 4: o[0] = o[1] = o[2] = (uint8_t)s[0]; o[3] = (uint8_t)s[1]; break;
-        case 6: o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; o[3] = (uint8_t)s[3]; break;
+        cur[i] = (uint8_t)v;
       }
     }
+    for (uint32_t y = 0; y < ps.h; ++y) {
+      const uint8_t* cur = raw.data() + passStart + (rowBytes + 1) * (size_t)y + 1;
+      for (uint32_t x = 0; x < ps.w; ++x) {
+        int s[4] = {0, 0, 0, 0};  // samples reduced to 8 bits (16-bit: high byte)
+        for (int k = 0; k < channels; ++k) {
+          const size_t idx = (size_t)x * channels + k;
+          if (depth == 16) s[k] = cur[idx * 2];
+          else if (depth == 8) s[k] = cur[idx];
+          else {
+            const size_t bit = idx * (size_t)depth;
+            s[k] = (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & maxv;
+          }
+        }
+        uint8_t* o = &rgba[((size_t)(ps.y0 + y * ps.dy) * w + (ps.x0 + x * ps.dx)) * 4];
+        switch (colorType) {
+          case 0: {
+            const int g = depth < 8 ? s[0] * 255 / maxv : s[0];
+            o[0] = o[1] = o[2] = (uint8_t)g;
+            break;
+          }
+          case 2: o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; break;
+          case 3: {
+            const size_t pi = (size_t)s[0];
+            if (pi * 3 + 2 >= palette.size()) throw std::runtime_error("PNG: palette index out of range");
+            o[0] = palette[pi * 3]; o[1] = palette[pi * 3 + 1]; o[2] = palette[pi * 3 + 2];
+            if (pi < trns.size()) o[3] = trns[pi];
+            break;
+          }
+          case 4: o[0] = o[1] = o[2] = (uint8_t)s[0]; o[3] = (uint8_t)s[1]; break;
+          case 6: o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; o[3] = (uint8_t)s[3]; break;
+        }
+      }
+    }
+    passStart += (rowBytes + 1) * (size_t)ps.h;
   }
   width = w;
   height = h;

@@ -1,4 +1,4 @@
-// Minimal PNG reader for glTF texture images: non-interlaced, bit depths 1-16, all five
+// PNG reader for glTF texture images: plain and interlaced (Adam7), bit depths 1-16, all five
 // colour types, palette transparency (tRNS); output is always RGBA8.  Inflate comes from zlib.
 #pragma once
 #include <cstddef>

@@ -62,6 +62,65 @@ def test_png_reader_matches_pil_for_all_filters_and_colour_types(textured, tmp_p
         assert np.array_equal(s.textures[0]["pixels"], ref), name
 
 
+def _write_interlaced_png(path, px):
+    """8-bit Adam7-interlaced PNG of px (h, w, channels 1..4), scan-line filters 0..4 in rotation."""
+    import struct
+    import zlib
+    h, w, c = px.shape
+    colour_type = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    x0, y0 = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1]
+    dx, dy = [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    raw = b""
+    for p in range(7):
+        sub = px[y0[p]::dy[p], x0[p]::dx[p]]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = np.zeros(sub.shape[1] * c, np.int32)
+        for r, row in enumerate(sub):
+            line = row.reshape(-1).astype(np.int32)
+            ft = (p + r) % 5
+            a = np.concatenate([np.zeros(c, np.int32), line[:-c]])
+            cc = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+            if ft == 0:
+                f = line
+            elif ft == 1:
+                f = line - a
+            elif ft == 2:
+                f = line - prev
+            elif ft == 3:
+                f = line - ((a + prev) >> 1)
+            else:
+                pp = a + prev - cc
+                pa, pb, pc = abs(pp - a), abs(pp - prev), abs(pp - cc)
+                f = line - np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, cc))
+            raw += bytes([ft]) + (f & 255).astype(np.uint8).tobytes()
+            prev = line
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, colour_type, 0, 0, 1)) +
+                 chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("shape", [(13, 21, 3), (1, 1, 4), (5, 3, 1), (9, 8, 2), (2, 30, 3)])
+def test_interlaced_png(tmp_path, shape):
+    """Adam7: seven reduced images, some of them empty for small sizes, each filtered on its own."""
+    px = np.random.default_rng(sum(shape)).integers(0, 256, shape, dtype=np.uint8)
+    _write_interlaced_png(str(tmp_path / "i.png"), px)
+    got = _one_texture_scene(tmp_path, "i.png").textures[0]["pixels"]
+    h, w, c = shape
+    ref = np.full((h, w, 4), 255, np.uint8)
+    if c <= 2:
+        ref[..., :3] = px[..., :1]
+        if c == 2:
+            ref[..., 3] = px[..., 1]
+    else:
+        ref[..., :c] = px
+    assert np.array_equal(got, ref)
+
+
 def _one_texture_scene(tmp_path, image_name):
     """A quad whose base colour texture is `image_name` (a file in tmp_path); returns the loaded scene."""
     g = scenes._GltfBuilder()
