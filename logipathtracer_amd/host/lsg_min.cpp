@@ -2,6 +2,7 @@
 #include "jpeg_decode.hpp"
 #include "png_decode.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -444,7 +445,37 @@ Ref<Object> buildNode(const Doc& d, size_t nodeIndex, const std::vector<Ref<Mesh
 
 std::vector<Ref<Scene>> GLTFLoader::load(const std::string& path) {
   Doc d;
-  d.root = minijson::parse(readFile(path, false));
+  std::string file = readFile(path, true);
+  std::string glbBin;  // binary chunk of a GLB container: the data of the buffer without uri
+  bool isGlb = false;
+  if (file.size() >= 12 && std::memcmp(file.data(), "glTF", 4) == 0) {
+    // Binary glTF: 12-byte header (magic, version, total length), then chunks of (length, type, data), the
+    // JSON document first (type "JSON"), optionally one binary chunk (type "BIN\0"); little-endian words.
+    isGlb = true;
+    auto le32 = [&](size_t o) {
+      const unsigned char* b = reinterpret_cast<const unsigned char*>(file.data()) + o;
+      return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+    };
+    if (le32(4) != 2u) throw std::runtime_error("glTF: binary container of a version other than 2");
+    const size_t total = std::min<size_t>(le32(8), file.size());
+    std::string json;
+    bool haveJson = false;
+    for (size_t o = 12; o + 8 <= total;) {
+      const size_t len = le32(o);
+      const uint32_t type = le32(o + 4);
+      if (len > total - o - 8) throw std::runtime_error("glTF: binary container chunk exceeds the file");
+      if (type == 0x4E4F534Au && !haveJson) {
+        json = file.substr(o + 8, len);
+        haveJson = true;
+      } else if (type == 0x004E4942u && glbBin.empty()) {
+        glbBin = file.substr(o + 8, len);
+      }
+      o += 8 + ((len + 3) & ~(size_t)3);
+    }
+    if (!haveJson) throw std::runtime_error("glTF: binary container without a JSON chunk");
+    file.swap(json);
+  }
+  d.root = minijson::parse(file);
   if (!d.root.isObject()) throw std::runtime_error("glTF: document is not a JSON object");
   size_t slash = path.find_last_of("/\\");
   d.dir = slash == std::string::npos ? "" : path.substr(0, slash + 1);
@@ -452,9 +483,11 @@ std::vector<Ref<Scene>> GLTFLoader::load(const std::string& path) {
   const Value& bufs = d.root["buffers"];
   for (size_t i = 0; i < bufs.size(); ++i) {
     std::string uri = bufs[i]["uri"].string();
-    if (uri.empty()) throw std::runtime_error("glTF: buffer without uri (GLB is not supported)");
     std::string data;
-    if (uri.compare(0, 5, "data:") == 0) {
+    if (uri.empty()) {
+      if (!isGlb || i != 0) throw std::runtime_error("glTF: buffer without uri outside a binary container");
+      data = glbBin;
+    } else if (uri.compare(0, 5, "data:") == 0) {
       size_t comma = uri.find(',');
       if (comma == std::string::npos) throw std::runtime_error("glTF: malformed data URI");
       data = decodeBase64(uri.substr(comma + 1));

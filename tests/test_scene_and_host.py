@@ -193,3 +193,36 @@ def test_builder_never_emits_leaves_beyond_the_device_limit(tmp_path, monkeypatc
         counts = leaves["indices"][:, 1].astype(np.int64) - leaves["indices"][:, 0]
         assert counts.sum() == 150 and counts.max() <= 63 and len(leaves) >= 3
         _check_tree(s.mesh_bvh, 0, 150)
+
+
+def _pack_glb(json_bytes, bin_bytes):
+    """Binary glTF container: header, JSON chunk (padded with spaces), BIN chunk (padded with zeros)."""
+    import struct
+    js = json_bytes + b" " * (-len(json_bytes) % 4)
+    chunks = struct.pack("<II", len(js), 0x4E4F534A) + js
+    if bin_bytes is not None:
+        bn = bin_bytes + b"\0" * (-len(bin_bytes) % 4)
+        chunks += struct.pack("<II", len(bn), 0x004E4942) + bn
+    return b"glTF" + struct.pack("<II", 2, 12 + len(chunks)) + chunks
+
+
+def test_binary_gltf_container_loads_like_the_text_form(tmp_path):
+    import json
+    import os
+    doc = json.load(open(CORNELL))
+    assert len(doc["buffers"]) == 1
+    bin_bytes = open(os.path.join(os.path.dirname(CORNELL), doc["buffers"][0]["uri"]), "rb").read()
+    del doc["buffers"][0]["uri"]
+    open(str(tmp_path / "cornell.glb"), "wb").write(_pack_glb(json.dumps(doc).encode(), bin_bytes))
+    a, b = L.Scene(CORNELL), L.Scene(str(tmp_path / "cornell.glb"))
+    for name in ("objects", "object_bvh", "vertices", "mesh_bvh"):
+        assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), name
+    assert np.array_equal(a.camera_world, b.camera_world) and a.fov_y == b.fov_y
+    # damaged containers fail with a message
+    good = open(str(tmp_path / "cornell.glb"), "rb").read()
+    open(str(tmp_path / "cut.glb"), "wb").write(good[:len(good) // 2])
+    with pytest.raises(L.LptError, match="glTF"):
+        L.Scene(str(tmp_path / "cut.glb"))
+    open(str(tmp_path / "nobin.glb"), "wb").write(_pack_glb(json.dumps(doc).encode(), None))
+    with pytest.raises(L.LptError, match="glTF"):
+        L.Scene(str(tmp_path / "nobin.glb"))
