@@ -226,9 +226,21 @@ void readAccessor(const Doc& d, long long index, int comps, bool asIndex, std::v
         else throw std::runtime_error("glTF: index accessor must be unsigned");
         out[i * comps + k] = (Out)v;
       } else {
-        if (ct != 5126) throw std::runtime_error("glTF: only float vertex attributes are supported");
         float v;
-        std::memcpy(&v, q, 4);
+        if (ct == 5126) {
+          std::memcpy(&v, q, 4);
+        } else if (acc["normalized"].boolean(false) && (ct == 5121 || ct == 5123)) {
+          // normalised unsigned integers (texture coordinates, colours): c / (2^bits - 1)
+          if (ct == 5121) v = (float)*(const uint8_t*)q / 255.0f;
+          else { uint16_t t; std::memcpy(&t, q, 2); v = (float)t / 65535.0f; }
+        } else if (acc["normalized"].boolean(false) && (ct == 5120 || ct == 5122)) {
+          // normalised signed integers (normals): max(c / (2^(bits-1) - 1), -1)
+          if (ct == 5120) v = (float)*(const int8_t*)q / 127.0f;
+          else { int16_t t; std::memcpy(&t, q, 2); v = (float)t / 32767.0f; }
+          if (v < -1.0f) v = -1.0f;
+        } else {
+          throw std::runtime_error("glTF: vertex attributes must be float or normalised integers");
+        }
         out[i * comps + k] = (Out)v;
       }
     }
@@ -355,14 +367,10 @@ Ref<Geometry> loadPrimitive(const Doc& d, const Value& prim) {
   for (uint32_t idx : g->indices)
     if (idx >= g->positions.size()) throw std::runtime_error("glTF: vertex index out of range");
   if (attrs.has("TEXCOORD_0")) {
-    const Value& acc = d.root["accessors"][(size_t)attrs["TEXCOORD_0"].integer(-1)];
-    if (acc["componentType"].integer(0) == 5126) {
-      readAccessor(d, attrs["TEXCOORD_0"].integer(-1), 2, false, tmp);
-      if (tmp.size() == g->positions.size() * 2) {
-        g->uvs.resize(tmp.size() / 2);
-        for (size_t i = 0; i < g->uvs.size(); ++i) g->uvs[i] = {tmp[2 * i], tmp[2 * i + 1]};
-      }
-    }
+    readAccessor(d, attrs["TEXCOORD_0"].integer(-1), 2, false, tmp);  // float or normalised unsigned integers
+    if (tmp.size() != g->positions.size() * 2) throw std::runtime_error("glTF: TEXCOORD_0 count differs from POSITION count");
+    g->uvs.resize(tmp.size() / 2);
+    for (size_t i = 0; i < g->uvs.size(); ++i) g->uvs[i] = {tmp[2 * i], tmp[2 * i + 1]};
   }
   if (attrs.has("NORMAL")) {
     readAccessor(d, attrs["NORMAL"].integer(-1), 3, false, tmp);

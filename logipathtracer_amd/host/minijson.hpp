@@ -41,6 +41,7 @@ class Value {
   double number(double fallback) const { return kind == Number ? num : fallback; }
   long long integer(long long fallback) const { return kind == Number ? (long long)num : fallback; }
   std::string string(const std::string& fallback = "") const { return kind == String ? str : fallback; }
+  bool boolean(bool fallback) const { return kind == Bool ? b : fallback; }
 };
 
 class Parser {

@@ -226,3 +226,40 @@ def test_binary_gltf_container_loads_like_the_text_form(tmp_path):
     open(str(tmp_path / "nobin.glb"), "wb").write(_pack_glb(json.dumps(doc).encode(), None))
     with pytest.raises(L.LptError, match="glTF"):
         L.Scene(str(tmp_path / "nobin.glb"))
+
+
+def test_normalised_integer_texture_coordinates(tmp_path):
+    """TEXCOORD_0 as normalised unsigned shorts (core glTF allows them) loads to the same floats."""
+    import json
+    import os
+    from logipathtracer_amd import scenes
+    scenes.write_textured_cornell(str(tmp_path / "t.gltf"))
+    doc = json.load(open(str(tmp_path / "t.gltf")))
+    bin_path = os.path.join(str(tmp_path), doc["buffers"][0]["uri"])
+    data = bytearray(open(bin_path, "rb").read())
+    changed = 0
+    for mesh in doc["meshes"]:
+        for prim in mesh["primitives"]:
+            a = prim["attributes"].get("TEXCOORD_0")
+            if a is None or doc["accessors"][a]["componentType"] != 5126:
+                continue
+            acc = doc["accessors"][a]
+            bv = doc["bufferViews"][acc["bufferView"]]
+            off = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
+            uv = np.frombuffer(bytes(data[off:off + acc["count"] * 8]), dtype=np.float32).reshape(-1, 2)
+            if uv.min() < 0 or uv.max() > 1:
+                continue
+            q = np.round(uv * 65535).astype(np.uint16)
+            assert np.array_equal(q.astype(np.float32) / np.float32(65535), uv)  # 0 and 1 only: exact
+            data += b"\0" * (-len(data) % 4)
+            doc["bufferViews"].append({"buffer": 0, "byteOffset": len(data), "byteLength": q.nbytes})
+            data += q.tobytes()
+            acc.update({"bufferView": len(doc["bufferViews"]) - 1, "byteOffset": 0, "componentType": 5123, "normalized": True})
+            changed += 1
+    assert changed
+    reference = L.Scene(str(tmp_path / "t.gltf"))
+    doc["buffers"][0]["byteLength"] = len(data)
+    open(bin_path, "wb").write(data)
+    json.dump(doc, open(str(tmp_path / "q.gltf"), "w"))
+    quantised = L.Scene(str(tmp_path / "q.gltf"))
+    assert reference.vertices.tobytes() == quantised.vertices.tobytes()
