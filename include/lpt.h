@@ -207,10 +207,11 @@ int lpt_set_options(lpt_ctx* ctx, int max_bounces, int bsdf_mode, int pipeline, 
 /* Renders n_frames consecutive frames (one sample per pixel each), frame i with
  * ubos[i]; equivalent to n_frames dispatches of path_tracing.comp::main
  * (shaders/path_tracing.comp:330-351) in order, including `reset` handling.
- * The call first waits for the work of the previous call on this context (as
- * RendererCore::drawFrame waits for its in-flight fence, src/RendererCore.cpp:376), then
- * queues the new work on the context's stream and returns without waiting for it, unless
- * n_frames exceeds the frames in flight: batches after the first wait for their predecessor. */
+ * The call queues its work on the context's stream behind whatever the stream still holds and
+ * returns without waiting for it, so the host may prepare the next call while the GPU renders this
+ * one (RendererCore::drawFrame waits for its single in-flight fence at this point,
+ * src/RendererCore.cpp:376; here the only wait is for the pinned staging buffer used two batches
+ * ago).  `ubos` is copied before the call returns.  lpt_get_stats reports the latest call. */
 int lpt_render_frames(lpt_ctx* ctx, const lpt_ubo* ubos, int n_frames);
 /* One frame; the call RendererPT::drawFrame lands on. */
 int lpt_render_frame(lpt_ctx* ctx, const lpt_ubo* ubo);

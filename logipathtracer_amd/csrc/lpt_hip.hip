@@ -692,7 +692,12 @@ struct lpt_ctx {
   float4* dSamples = nullptr;
   uint32_t* dCounts = nullptr;   // [poolBounces] queue fills, then [poolBounces][kCursorRegions] ray cursors of k_extend
   lpt_ubo* dUbos = nullptr;
-  lpt_ubo* hUbos = nullptr;  // pinned staging
+  // Pinned staging of the frames' uniform blocks (+ one word behind them), two buffers used in turn: a call may
+  // be enqueued while the previous one still runs; evStaging[k] says when the copy out of buffer k is done.
+  lpt_ubo* hUbos[2] = {nullptr, nullptr};
+  hipEvent_t evStaging[2] = {nullptr, nullptr};
+  bool stagingBusy[2] = {false, false};
+  int stagingNext = 0;
   int ubosCap = 0;
   unsigned long long* dTotals = nullptr;  // [0] paths, [1] segments
   // Words the kernels raise when they give up: pinned host memory the device writes through its mapped
@@ -937,13 +942,37 @@ int ensure_pool(lpt_ctx* c, int frames) {
     c->poolBounces = c->maxBounces + 1;
   }
   if (frames > c->ubosCap) {
+    LPT_HIP(c, hipStreamSynchronize(c->stream));  // copies out of the old staging buffers are done
     dfree(c->dUbos);
-    if (c->hUbos) (void)hipHostFree(c->hUbos);
-    c->hUbos = nullptr;
+    c->ubosCap = 0;
+    for (int k = 0; k < 2; ++k) {
+      if (c->hUbos[k]) (void)hipHostFree(c->hUbos[k]);
+      c->hUbos[k] = nullptr;
+      c->stagingBusy[k] = false;
+    }
     LPT_HIP(c, hipMalloc(&c->dUbos, (size_t)frames * sizeof(lpt_ubo)));
-    LPT_HIP(c, hipHostMalloc(&c->hUbos, ((size_t)frames + 1) * sizeof(lpt_ubo)));
+    for (int k = 0; k < 2; ++k) LPT_HIP(c, hipHostMalloc(&c->hUbos[k], ((size_t)frames + 1) * sizeof(lpt_ubo)));
     c->ubosCap = frames;
   }
+  return 0;
+}
+
+// The uniform blocks of a batch to c->dUbos and, with `firstQueueFill`, the number of camera paths to
+// c->dCounts[0] (the first queue is filled in path-id order, so its count is known here), through the pinned
+// staging buffer whose turn it is.  Waits only if that buffer's previous copy (two batches ago) is still pending.
+int stage_frames(lpt_ctx* c, const lpt_ubo* ubos, int frames, bool firstQueueFill) {
+  const int k = c->stagingNext;
+  if (c->stagingBusy[k]) LPT_HIP(c, hipEventSynchronize(c->evStaging[k]));
+  lpt_ubo* h = c->hUbos[k];
+  std::memcpy(h, ubos, (size_t)frames * sizeof(lpt_ubo));
+  LPT_HIP(c, hipMemcpyAsync(c->dUbos, h, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
+  if (firstQueueFill) {
+    h[frames].seed[0] = (uint32_t)frames * c->nValid;  // staging word behind the frame blocks
+    LPT_HIP(c, hipMemcpyAsync(c->dCounts, &h[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  }
+  LPT_HIP(c, hipEventRecord(c->evStaging[k], c->stream));
+  c->stagingBusy[k] = true;
+  c->stagingNext = k ^ 1;
   return 0;
 }
 
@@ -1024,13 +1053,10 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
-  std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
-  LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
   LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorRegions) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   uint32_t* cursors = c->dCounts + c->poolBounces;
-  // the first queue is filled in path-id order, its count is known here
-  c->hUbos[frames].seed[0] = (uint32_t)frames * c->nValid;  // staging word behind the frame blocks
-  LPT_HIP(c, hipMemcpyAsync(c->dCounts, &c->hUbos[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  rc = stage_frames(c, ubos, frames, true);
+  if (rc) return rc;
   if (c->nValid && !primary_packets())  // the packet kernel generates the camera rays itself
     hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                        (uint32_t)frames, c->queues[0], c->dValidBefore, c->nValid);
@@ -1103,8 +1129,8 @@ void dispatch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& 
 int render_batch_persistent(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   int rc = ensure_pool(c, frames);
   if (rc) return rc;
-  std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
-  LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
+  rc = stage_frames(c, ubos, frames, false);
+  if (rc) return rc;
   LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, kCursorRegions * sizeof(uint32_t), c->stream));
   rc = ensure_events(c, c->evUsed + 2);
   if (rc) return rc;
@@ -1125,12 +1151,10 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
-  std::memcpy(c->hUbos, ubos, (size_t)frames * sizeof(lpt_ubo));
-  LPT_HIP(c, hipMemcpyAsync(c->dUbos, c->hUbos, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
   LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorRegions) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   uint32_t* cursors = c->dCounts + c->poolBounces;  // poolBounces >= 2: regions of bounce 0 and bounce 1 exist
-  c->hUbos[frames].seed[0] = (uint32_t)frames * c->nValid;  // staging word behind the frame blocks
-  LPT_HIP(c, hipMemcpyAsync(c->dCounts, &c->hUbos[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  rc = stage_frames(c, ubos, frames, true);
+  if (rc) return rc;
   rc = ensure_events(c, c->evUsed + 2);
   if (rc) return rc;
   const Queue& q0 = c->queues[0];
@@ -1269,6 +1293,8 @@ int lpt_create(int device, lpt_ctx** out) {
   c->stream = c->ownStream;
   if ((e = hipEventCreate(&c->evStart)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->evStop)) != hipSuccess) return bail("hipEventCreate", e);
+  for (int k = 0; k < 2; ++k)
+    if ((e = hipEventCreateWithFlags(&c->evStaging[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&c->dTotals, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   // this GPU's copy of the static scratch array (the device is current here)
@@ -1297,7 +1323,10 @@ void lpt_destroy(lpt_ctx* c) {
   dfree(c->dValidBefore);
   dfree(c->dUbos);
   dfree(c->dTotals);
-  if (c->hUbos) (void)hipHostFree(c->hUbos);
+  for (int k = 0; k < 2; ++k) {
+    if (c->hUbos[k]) (void)hipHostFree(c->hUbos[k]);
+    if (c->evStaging[k]) (void)hipEventDestroy(c->evStaging[k]);
+  }
   if (c->hFlags) (void)hipHostFree(const_cast<uint32_t*>(c->hFlags));
   for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
   if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -1623,10 +1652,11 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   if (rc) return rc;
   if (!ubos || n_frames <= 0) return fail(c, LPT_ERR_INVALID, "no frames");
   LPT_USE_DEVICE(c);
-  // the previous call's events and pinned staging must be free again (RendererCore::drawFrame waits for
-  // its in-flight fence in the same place, src/RendererCore.cpp:376)
-  LPT_HIP(c, hipStreamSynchronize(c->stream));
-  rc = check_flags(c);  // the previous call's render was cut short and nobody has asked since
+  // Enqueues behind whatever the stream still holds: the queues, counters and images are only touched in stream
+  // order, the pinned staging alternates between two buffers (stage_frames), and the timing events are simply
+  // recorded again — statistics are those of the latest call.  (RendererCore::drawFrame waits for its single
+  // in-flight fence here, src/RendererCore.cpp:376; this layer allows the host to run one call ahead of the GPU.)
+  rc = check_flags(c);  // an earlier render was cut short and nobody has asked since
   if (rc) return rc;
   c->evUsed = 0;
   c->haveTiming = false;
@@ -1669,7 +1699,6 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     if (rc) return rc;
     for (int f = 0; f < n_frames; f += fif) {
       int nb = std::min(fif, n_frames - f);
-      if (f > 0) LPT_HIP(c, hipStreamSynchronize(c->stream));  // pinned ubo staging is reused
       rc = c->activePipeline == LPT_PIPELINE_PERSISTENT ? render_batch_persistent(c, ubos + f, nb)
            : c->activePipeline == LPT_PIPELINE_HYBRID   ? render_batch_hybrid(c, ubos + f, nb)
                                                         : render_batch_wavefront(c, ubos + f, nb);
