@@ -43,8 +43,22 @@ __device__ unsigned long long g_extendStats[16 + 64];
 // Rays are handed out in chunks of kFetchChunk.  The queue is cut into kCursorRegions equal
 // regions with one cursor each (a single atomic word would serialise all waves); a wave
 // starts in the region of its workgroup and moves on to the next one when it runs dry.
-constexpr uint32_t kFetchChunk = 128;
-constexpr uint32_t kCursorRegions = 8;
+#ifndef LPT_FETCH_CHUNK
+#define LPT_FETCH_CHUNK 128
+#endif
+constexpr uint32_t kFetchChunk = LPT_FETCH_CHUNK;
+#ifndef LPT_CURSOR_REGIONS
+#define LPT_CURSOR_REGIONS 8
+#endif
+constexpr uint32_t kCursorRegions = LPT_CURSOR_REGIONS;
+// Every cursor has a cache line of its own: atomics on words of one line are carried out one after the other
+// (about 100 per microsecond), and the 7 168 waves of a launch issue several hundred thousand of them.
+#ifndef LPT_CURSOR_STRIDE
+#define LPT_CURSOR_STRIDE 64
+#endif
+constexpr uint32_t kCursorStride = LPT_CURSOR_STRIDE;               // words between two cursors
+constexpr uint32_t kCursorWords = kCursorRegions * kCursorStride;  // one set of cursors
+
 #ifndef LPT_FETCH_THRESHOLD
 #define LPT_FETCH_THRESHOLD 16
 #endif
@@ -127,7 +141,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       while (!exhausted && chunkNext >= chunkEnd) {
         const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
         uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&cursor[region], kFetchChunk);
+        if (lane == 0) b = atomicAdd(&cursor[region * kCursorStride], kFetchChunk);
         b = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
         if (lo < hi && b < hi) {
           chunkNext = b;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
 }
 
 // Closest hit for every queued ray: persistent waves, node stacks in LDS, rays handed out
-// through `cursor` (kCursorRegions words zeroed before the launch).  See lpt_extend.h.
+// through `cursor` (one set of cursors, kCursorWords words zeroed before the launch).  See lpt_extend.h.
 template <int S>
 __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
                                                    const float4* __restrict__ qd, const uint32_t* __restrict__ count,
@@ -481,7 +481,7 @@ __global__ void k_tally(const uint32_t* __restrict__ counts, uint32_t nBounces, 
 // ---- persistent path tracer ----------------------------------------------------------
 
 // Traces every path of a batch of frames from ray generation to its radiance in `samples`
-// (lpt_trace.h).  `cursor` = kCursorRegions zeroed words.
+// (lpt_trace.h).  `cursor` = one zeroed set of cursors (kCursorWords words).
 #ifndef LPT_TRACE_WAVES_PER_SIMD
 #define LPT_TRACE_WAVES_PER_SIMD 4
 #endif
@@ -625,12 +625,13 @@ __global__ __launch_bounds__(kBlock) void k_debug_intersect(DScene sc, const flo
 
 // ---- scratch of the entry point that allocates nothing (lpt_render_frame_static) ---------------
 // One array per GPU, held from the moment the library is loaded on it until the process ends.  Layout:
-// [0, 1 KiB) the ray cursors of the persistent launch and the frame's uniform block, then one RGBA32F
+// [0, 16 KiB) the ray cursors of the persistent launch and the frame's uniform block, then one RGBA32F
 // sample per owned pixel slot.  The name below is a host-side stand-in: host code uses the device address
 // lpt_create obtains with hipGetSymbolAddress (lpt_ctx::dStatic), never the name.
 constexpr uint32_t kStaticMaxSlots = 2304u * 1024u;  // 2 359 296 pixel slots: up to 1920x1080 (36 MiB of samples)
-constexpr size_t kStaticHeaderBytes = 1024;
-constexpr size_t kStaticUboOffset = 256;
+constexpr size_t kStaticHeaderBytes = 16384;
+constexpr size_t kStaticUboOffset = kCursorWords * sizeof(uint32_t);
+static_assert(kStaticUboOffset + sizeof(lpt_ubo) <= kStaticHeaderBytes, "cursors and uniform block fit the header");
 constexpr size_t kStaticBytes = kStaticHeaderBytes + (size_t)kStaticMaxSlots * sizeof(float4);
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
@@ -690,7 +691,7 @@ struct lpt_ctx {
   Queue queues[2]{};
   float4* dHits = nullptr;
   float4* dSamples = nullptr;
-  uint32_t* dCounts = nullptr;   // [poolBounces] queue fills, then [poolBounces][kCursorRegions] ray cursors of k_extend
+  uint32_t* dCounts = nullptr;   // [poolBounces] queue fills, then [poolBounces][kCursorWords] ray cursors of k_extend
   lpt_ubo* dUbos = nullptr;
   // Pinned staging of the frames' uniform blocks (+ one word behind them), two buffers used in turn: a call may
   // be enqueued while the previous one still runs; evStaging[k] says when the copy out of buffer k is done.
@@ -938,7 +939,7 @@ int ensure_pool(lpt_ctx* c, int frames) {
   }
   if (c->maxBounces + 1 > c->poolBounces) {
     dfree(c->dCounts);
-    LPT_HIP(c, hipMalloc(&c->dCounts, (1 + kCursorRegions) * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
+    LPT_HIP(c, hipMalloc(&c->dCounts, (1 + kCursorWords) * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
     c->poolBounces = c->maxBounces + 1;
   }
   if (frames > c->ubosCap) {
@@ -1053,7 +1054,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorRegions) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorWords) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   uint32_t* cursors = c->dCounts + c->poolBounces;
   rc = stage_frames(c, ubos, frames, true);
   if (rc) return rc;
@@ -1077,14 +1078,14 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
       launch_primary(c, in, frames);
     } else {  // the k_extend launches are timed one by one (lpt_stats.extend_ms)
       LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-      dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorRegions, paths);
+      dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorWords, paths);
       LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     }
     launch_shade(c, in, out, b, nB, paths);
   }
   if (tail < nB) {
     const Queue& q = c->queues[tail & 1];
-    dispatch_trace<true>(c, frames, cursors + (size_t)tail * kCursorRegions,
+    dispatch_trace<true>(c, frames, cursors + (size_t)tail * kCursorWords,
                          TraceQueue{q.o, q.d, q.m, c->dCounts + tail, tail, 0u});
   }
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
@@ -1095,7 +1096,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   return 0;
 }
 
-// QUEUED: the paths come from `src` (at most frames * slots entries), `cursor` = kCursorRegions zeroed words.
+// QUEUED: the paths come from `src` (at most frames * slots entries), `cursor` = one zeroed set of cursors.
 template <int S, bool QUEUED>
 void launch_trace(lpt_ctx* c, int frames, uint32_t* cursor, const TraceQueue& src, const lpt_ubo* ubos, float4* samples) {
   // persistent grid: exactly as many workgroups as are resident at once (registers and LDS decide)
@@ -1131,7 +1132,7 @@ int render_batch_persistent(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   rc = stage_frames(c, ubos, frames, false);
   if (rc) return rc;
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, kCursorRegions * sizeof(uint32_t), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, kCursorWords * sizeof(uint32_t), c->stream));
   rc = ensure_events(c, c->evUsed + 2);
   if (rc) return rc;
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
@@ -1151,7 +1152,7 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorRegions) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorWords) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   uint32_t* cursors = c->dCounts + c->poolBounces;  // poolBounces >= 2: regions of bounce 0 and bounce 1 exist
   rc = stage_frames(c, ubos, frames, true);
   if (rc) return rc;
@@ -1174,7 +1175,7 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   }
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   if (nB > 1 && c->nValid)
-    dispatch_trace<true>(c, frames, cursors + kCursorRegions, TraceQueue{q1.o, q1.d, q1.m, c->dCounts + 1, 1u, 1u});
+    dispatch_trace<true>(c, frames, cursors + kCursorWords, TraceQueue{q1.o, q1.d, q1.m, c->dCounts + 1, 1u, 1u});
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
@@ -1732,7 +1733,7 @@ int lpt_render_frame_static(lpt_ctx* c, const lpt_ubo* ubo) {
   c->haveTiming = false;
   c->activePipeline = LPT_PIPELINE_PERSISTENT;
   LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long), c->stream));
-  LPT_HIP(c, hipMemsetAsync(cursor, 0, kCursorRegions * sizeof(uint32_t), c->stream));  // the last call's cursors
+  LPT_HIP(c, hipMemsetAsync(cursor, 0, kCursorWords * sizeof(uint32_t), c->stream));  // the last call's cursors
   LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
   hipLaunchKernelGGL(k_store_ubo, dim3(1), dim3(64), 0, c->stream, *ubo, dUbo);
   if (c->nValid)

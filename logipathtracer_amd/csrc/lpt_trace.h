@@ -65,7 +65,7 @@ struct TraceQueue {
   uint32_t timed;  // this launch is the one whose time the statistics report: its segments go to totals[16] too
 };
 
-// `cursor` holds kCursorRegions zeroed words; `totals[0]` counts paths, `totals[1]` ray segments, `totals[16]`
+// `cursor` holds one zeroed set of cursors (kCursorWords words); `totals[0]` counts paths, `totals[1]` ray segments, `totals[16]`
 // the segments of timed launches
 // (QUEUED: only the segments traced here are added).
 template <int S, int BLOCK, bool QUEUED>
@@ -226,7 +226,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
         while (!exhausted && chunkNext >= chunkEnd) {
           const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
           uint32_t b = 0;
-          if (lane == 0) b = atomicAdd(&cursor[region], kFetchChunk);
+          if (lane == 0) b = atomicAdd(&cursor[region * kCursorStride], kFetchChunk);
           b = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
           if (lo < hi && b < hi) {
             chunkNext = b;
