@@ -40,9 +40,9 @@ __device__ unsigned long long g_extendStats[16 + 64];
 #define LPT_XSTAT(k, lanes) ((void)0)
 #endif
 
-// Rays are handed out in chunks of kFetchChunk.  The queue is cut into kCursorRegions equal
-// regions with one cursor each (a single atomic word would serialise all waves); a wave
-// starts in the region of its workgroup and moves on to the next one when it runs dry.
+// Rays are handed out in chunks of kFetchChunk.  The queue consists of kCursorRegions regions (its
+// part queues, see QueueFill) with one cursor each (a single atomic word would serialise all waves); a
+// wave starts in the region of its workgroup and moves on to the next one when it runs dry.
 #ifndef LPT_FETCH_CHUNK
 #define LPT_FETCH_CHUNK 128
 #endif
@@ -58,6 +58,18 @@ constexpr uint32_t kCursorRegions = LPT_CURSOR_REGIONS;
 #endif
 constexpr uint32_t kCursorStride = LPT_CURSOR_STRIDE;               // words between two cursors
 constexpr uint32_t kCursorWords = kCursorRegions * kCursorStride;  // one set of cursors
+
+// A path queue is kept as kCursorRegions part queues of `capPart` entries each: part r holds its entries at
+// [r * capPart, r * capPart + fill[r]), and fill[r] is word r * kCursorStride of the queue's set of fill counts
+// (laid out like a set of cursors, for the same reason: the appending kernels add to them with atomics, one per
+// workgroup, several hundred thousand per launch).  A workgroup appends to the part of its own number modulo
+// kCursorRegions, which is also the region its waves take rays from first: consecutive workgroups run on
+// different XCDs, so a part is mostly written and read through one XCD's L2.
+struct QueueFill {
+  const uint32_t* fill;  // set of fill counts
+  uint32_t capPart;      // entries per part queue
+};
+__device__ __forceinline__ uint32_t part_fill(const QueueFill& q, uint32_t part) { return q.fill[part * kCursorStride]; }
 
 #ifndef LPT_FETCH_THRESHOLD
 #define LPT_FETCH_THRESHOLD 16
@@ -84,7 +96,7 @@ constexpr int kCacheStride = 20;
 // CACHE * kCacheStride words (unused if CACHE == 0).
 template <int S, int BLOCK, int CACHE>
 __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4* __restrict__ qo,
-                                                  const float4* __restrict__ qd, uint32_t n,
+                                                  const float4* __restrict__ qd, const QueueFill& fill,
                                                   float4* __restrict__ hits, uint32_t* cursor, uint32_t* stack,
                                                   float* cache) {
   uint32_t* stk = &stack[threadIdx.x];
@@ -99,8 +111,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
   // wave-uniform chunk of ray indices [chunkNext, chunkEnd)
   uint32_t chunkNext = 0, chunkEnd = 0;
   bool exhausted = false;
-  const uint32_t regionSize = (n + kCursorRegions - 1u) / kCursorRegions;
-  uint32_t region = blockIdx.x % kCursorRegions;  // region being drained
+  uint32_t region = blockIdx.x % kCursorRegions;  // region (part queue) being drained
   uint32_t regionsTried = 0;
 
   int state = kStFetch;
@@ -139,13 +150,15 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     if (nF > 0 && (nF >= LPT_FETCH_THRESHOLD || busy == 0)) {
       LPT_XSTAT(0, nF);
       while (!exhausted && chunkNext >= chunkEnd) {
-        const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&cursor[region * kCursorStride], kFetchChunk);
-        b = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
-        if (lo < hi && b < hi) {
-          chunkNext = b;
-          chunkEnd = min(b + kFetchChunk, hi);
+        const uint32_t lo = region * fill.capPart, size = part_fill(fill, region);
+        uint32_t b = size;
+        if (size != 0u) {
+          if (lane == 0) b = atomicAdd(&cursor[region * kCursorStride], kFetchChunk);
+          b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
+        }
+        if (b < size) {
+          chunkNext = lo + b;
+          chunkEnd = lo + min(b + kFetchChunk, size);
         } else {
           region = (region + 1u) % kCursorRegions;
           if (++regionsTried >= kCursorRegions) exhausted = true;

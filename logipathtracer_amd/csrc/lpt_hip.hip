@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
 // through `cursor` (one set of cursors, kCursorWords words zeroed before the launch).  See lpt_extend.h.
 template <int S>
 __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
-                                                   const float4* __restrict__ qd, const uint32_t* __restrict__ count,
+                                                   const float4* __restrict__ qd, QueueFill fill,
                                                    float4* __restrict__ hits, uint32_t* cursor) {
 // The 24 hottest nodes (the top of the object tree) in LDS: what fits beside the stacks without costing
 // a resident workgroup.  Measured: -2 % kernel time on the Cornell box, -6 % on a 70-object scene; 32 and
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __re
 #endif
   __shared__ uint32_t stack[S * kBlock];
   __shared__ __attribute__((aligned(16))) float cache[LPT_EXTEND_CACHE_NODES > 0 ? LPT_EXTEND_CACHE_NODES * kCacheStride : 4];
-  extend_persistent<S, kBlock, LPT_EXTEND_CACHE_NODES>(sc, qo, qd, *count, hits, cursor, stack, cache);
+  extend_persistent<S, kBlock, LPT_EXTEND_CACHE_NODES>(sc, qo, qd, fill, hits, cursor, stack, cache);
 }
 
 // Camera rays of a batch: generated, queued for the shading kernel and traced, 64 consecutive path ids
@@ -305,14 +305,20 @@ constexpr int kShadeClasses = 3;
 #endif
 __attribute__((amdgpu_waves_per_eu(LPT_SHADE_WAVES_PER_SIMD, LPT_SHADE_WAVES_PER_SIMD)))
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const float4* __restrict__ hits,
-                                                  const uint32_t* __restrict__ countIn, Queue out, uint32_t* countOut,
+                                                  QueueFill fillIn, Queue out, uint32_t* fillOut,
                                                   float4* __restrict__ samples, uint32_t bounce, uint32_t maxBounces,
                                                   int bsdfMode) {
   __shared__ uint32_t lds[kBlock / 64 + 1];
   __shared__ uint32_t waveCount[kShadeClasses][kBlock / 64];
   __shared__ uint32_t pending[kShadeClasses][2 * kBlock];  // fewer than kBlock entries each between scans
   __shared__ WalkShared walk;
-  const uint32_t n = *countIn;
+  // This workgroup's part of the queue (its own number modulo the parts; the grid is a multiple of them): it
+  // shades that part's entries together with the other workgroups of the same part, and what goes on is
+  // appended to the same part of `out`, which therefore never holds more than the input part did.
+  const uint32_t part = blockIdx.x % kCursorRegions, rank = blockIdx.x / kCursorRegions;
+  const uint32_t blocksOfPart = gridDim.x / kCursorRegions;
+  const uint32_t lo = part * fillIn.capPart, n = lo + part_fill(fillIn, part);  // entries [lo, n)
+  uint32_t* countOut = fillOut + part * kCursorStride;
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t nPending[kShadeClasses] = {0u, 0u, 0u};  // same values in every thread of the block
 
@@ -345,12 +351,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
       settle_entry(samples, p, pidWord, alive);
     }
     const uint32_t carry = threadIdx.x + kBlock < count ? pending[c][threadIdx.x + kBlock] : 0u;
-    const uint32_t dst = block_append(alive, countOut, lds);  // synchronises the block
+    const uint32_t dst = lo + block_append(alive, countOut, lds);  // synchronises the block
     if (alive) store_path(out, dst, p, pidWord);
     if (threadIdx.x + kBlock < count) pending[c][threadIdx.x] = carry;
   };
 
-  for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+  for (uint32_t base = lo + rank * kBlock; base < n; base += blocksOfPart * kBlock) {
     const uint32_t i = base + threadIdx.x;
     uint32_t cls = kShadeClasses;  // none
     if (i < n) {
@@ -407,7 +413,7 @@ __attribute__((amdgpu_waves_per_eu(LPT_PRIMARY_WAVES_PER_SIMD, LPT_PRIMARY_WAVES
 __global__ __launch_bounds__(kBlock) void k_primary_shade(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
                                                           const ObjTrav* __restrict__ otrav, DScene sc, Partition P,
                                                           const lpt_ubo* __restrict__ ubos, uint32_t nFrames, Queue out,
-                                                          uint32_t* countOut, float4* __restrict__ samples,
+                                                          uint32_t* fillOut, uint32_t capPart, float4* __restrict__ samples,
                                                           uint32_t maxBounces, int bsdfMode) {
   __shared__ uint32_t lds[kBlock / 64 + 1];
   __shared__ WalkShared walk;
@@ -438,7 +444,10 @@ __global__ __launch_bounds__(kBlock) void k_primary_shade(const TNode* __restric
       samples[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   }
-  const uint32_t dst = block_append(alive, countOut, lds);
+  // appended to the part queue of this workgroup's number: at most one workgroup's paths per kCursorRegions
+  // workgroups land there, which is what the parts are sized for
+  const uint32_t part = blockIdx.x % kCursorRegions;
+  const uint32_t dst = part * capPart + block_append(alive, fillOut + part * kCursorStride, lds);
   if (alive) store_path(out, dst, p, pidWord);
 }
 
@@ -463,16 +472,20 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Partition P, const lpt_ub
 }
 
 // totals[0] += paths started, totals[1] += ray segments traced (queue fills per bounce), totals[16] += those
-// of the bounces from `timedFrom` on (the ones whose extend launches are timed).
-__global__ void k_tally(const uint32_t* __restrict__ counts, uint32_t nBounces, uint32_t timedFrom,
+// of the bounces from `timedFrom` on (the ones whose extend launches are timed).  `fills`: one set of fill
+// counts per bounce.
+__global__ void k_tally(const uint32_t* __restrict__ fills, uint32_t nBounces, uint32_t timedFrom,
                         unsigned long long* totals) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    unsigned long long seg = 0, timed = 0;
+    unsigned long long seg = 0, timed = 0, first = 0;
     for (uint32_t b = 0; b < nBounces; ++b) {
-      seg += counts[b];
-      if (b >= timedFrom) timed += counts[b];
+      unsigned long long n = 0;
+      for (uint32_t r = 0; r < kCursorRegions; ++r) n += fills[b * kCursorWords + r * kCursorStride];
+      seg += n;
+      if (b >= timedFrom) timed += n;
+      if (b == 0) first = n;
     }
-    totals[0] += counts[0];
+    totals[0] += first;
     totals[1] += seg;
     totals[16] += timed;
   }
@@ -685,13 +698,14 @@ struct lpt_ctx {
 
   // wavefront pool
   size_t poolPaths = 0;
+  uint32_t capPart = 0;  // entries per part queue: the queue arrays hold kCursorRegions * capPart entries
   int poolArrays = 0;  // float4 arrays per path in dPool: 8 (wavefront) or 1 (persistent: samples only)
   int poolBounces = 0;
   float4* dPool = nullptr;  // 2 queues x 3 arrays + hits + samples
   Queue queues[2]{};
   float4* dHits = nullptr;
   float4* dSamples = nullptr;
-  uint32_t* dCounts = nullptr;   // [poolBounces] queue fills, then [poolBounces][kCursorWords] ray cursors of k_extend
+  uint32_t* dCounts = nullptr;   // [poolBounces] sets of queue fill counts, then [poolBounces] sets of ray cursors
   lpt_ubo* dUbos = nullptr;
   // Pinned staging of the frames' uniform blocks (+ one word behind them), two buffers used in turn: a call may
   // be enqueued while the previous one still runs; evStaging[k] says when the copy out of buffer k is done.
@@ -916,7 +930,14 @@ int ensure_pool(lpt_ctx* c, int frames) {
   if (paths > c->poolPaths || arrays != c->poolArrays) {
     dfree(c->dPool);
     c->poolPaths = 0;
-    if (hipMalloc(&c->dPool, paths * arrays * sizeof(float4)) != hipSuccess) {
+    // A queue array holds kCursorRegions part queues.  A part receives the paths of every kCursorRegions-th
+    // workgroup of the kernel that starts the paths (256 each), later kernels keep every path in its part:
+    // ceil(workgroups / parts) * 256 entries hold whatever happens.  One array of `paths` entries for the samples.
+    const size_t blocks = (paths + kBlock - 1) / kBlock;
+    const size_t capPart = ((blocks + kCursorRegions - 1) / kCursorRegions) * kBlock;
+    const size_t entries = capPart * kCursorRegions;
+    if (entries >= (1ull << 32)) return fail(c, LPT_ERR_INVALID, "too many paths in flight for 32-bit queue indices");
+    if (hipMalloc(&c->dPool, ((size_t)(arrays - 1) * entries + paths) * sizeof(float4)) != hipSuccess) {
       (void)hipGetLastError();
       c->dPool = nullptr;
       return fail(c, LPT_ERR_NOMEM, "not enough device memory for " + std::to_string(frames) + " frames in flight");
@@ -925,21 +946,22 @@ int ensure_pool(lpt_ctx* c, int frames) {
     c->queues[0] = c->queues[1] = Queue{nullptr, nullptr, nullptr};
     c->dHits = nullptr;
     for (int q = arrays == 8 ? 0 : 1; q < 2 && arrays > 1; ++q) {
-      c->queues[q].o = p; p += paths;
-      c->queues[q].d = p; p += paths;
-      c->queues[q].m = p; p += paths;
+      c->queues[q].o = p; p += entries;
+      c->queues[q].d = p; p += entries;
+      c->queues[q].m = p; p += entries;
     }
     if (arrays == 8) {
-      c->dHits = p; p += paths;
+      c->dHits = p; p += entries;
     }
     c->dSamples = p;
+    c->capPart = (uint32_t)capPart;
     LPT_HIP(c, hipMemsetAsync(c->dSamples, 0, paths * sizeof(float4), c->stream));
     c->poolPaths = paths;
     c->poolArrays = arrays;
   }
   if (c->maxBounces + 1 > c->poolBounces) {
     dfree(c->dCounts);
-    LPT_HIP(c, hipMalloc(&c->dCounts, (1 + kCursorWords) * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
+    LPT_HIP(c, hipMalloc(&c->dCounts, 2 * kCursorWords * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
     c->poolBounces = c->maxBounces + 1;
   }
   if (frames > c->ubosCap) {
@@ -952,15 +974,18 @@ int ensure_pool(lpt_ctx* c, int frames) {
       c->stagingBusy[k] = false;
     }
     LPT_HIP(c, hipMalloc(&c->dUbos, (size_t)frames * sizeof(lpt_ubo)));
-    for (int k = 0; k < 2; ++k) LPT_HIP(c, hipHostMalloc(&c->hUbos[k], ((size_t)frames + 1) * sizeof(lpt_ubo)));
+    for (int k = 0; k < 2; ++k)  // the frames' blocks and one set of fill counts behind them
+      LPT_HIP(c, hipHostMalloc(&c->hUbos[k], (size_t)frames * sizeof(lpt_ubo) + kCursorWords * sizeof(uint32_t)));
     c->ubosCap = frames;
   }
   return 0;
 }
 
-// The uniform blocks of a batch to c->dUbos and, with `firstQueueFill`, the number of camera paths to
-// c->dCounts[0] (the first queue is filled in path-id order, so its count is known here), through the pinned
-// staging buffer whose turn it is.  Waits only if that buffer's previous copy (two batches ago) is still pending.
+// The uniform blocks of a batch to c->dUbos and, with `firstQueueFill`, the fill counts of the first queue to
+// the first set of c->dCounts (that queue is filled densely in path-id order, if it is written at all: its
+// parts are full one after the other; the counts also tell k_tally how many paths were started), through the
+// pinned staging buffer whose turn it is.  Waits only if that buffer's previous copy (two batches ago) is still
+// pending.
 int stage_frames(lpt_ctx* c, const lpt_ubo* ubos, int frames, bool firstQueueFill) {
   const int k = c->stagingNext;
   if (c->stagingBusy[k]) LPT_HIP(c, hipEventSynchronize(c->evStaging[k]));
@@ -968,8 +993,15 @@ int stage_frames(lpt_ctx* c, const lpt_ubo* ubos, int frames, bool firstQueueFil
   std::memcpy(h, ubos, (size_t)frames * sizeof(lpt_ubo));
   LPT_HIP(c, hipMemcpyAsync(c->dUbos, h, (size_t)frames * sizeof(lpt_ubo), hipMemcpyHostToDevice, c->stream));
   if (firstQueueFill) {
-    h[frames].seed[0] = (uint32_t)frames * c->nValid;  // staging word behind the frame blocks
-    LPT_HIP(c, hipMemcpyAsync(c->dCounts, &h[frames].seed[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    uint32_t* fills = reinterpret_cast<uint32_t*>(h + frames);
+    std::memset(fills, 0, kCursorWords * sizeof(uint32_t));
+    size_t left = (size_t)frames * c->nValid;
+    for (uint32_t r = 0; r < kCursorRegions; ++r) {
+      const size_t take = std::min<size_t>(left, c->capPart);
+      fills[r * kCursorStride] = (uint32_t)take;
+      left -= take;
+    }
+    LPT_HIP(c, hipMemcpyAsync(c->dCounts, fills, kCursorWords * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   }
   LPT_HIP(c, hipEventRecord(c->evStaging[k], c->stream));
   c->stagingBusy[k] = true;
@@ -984,7 +1016,7 @@ int grid_for(const lpt_ctx* c, size_t items, int blocksPerCU) {
 }
 
 template <int S>
-int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
+int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* cursor, size_t maxItems) {
   // persistent grid: exactly as many workgroups as are resident at once (registers and LDS decide)
   static const int resident = [] {
     int n = 0;
@@ -996,20 +1028,25 @@ int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* c
   if (capPerCU > 0) perCU = std::min(perCU, capPerCU);
   size_t need = (maxItems + kBlock - 1) / kBlock;
   int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
-  hipLaunchKernelGGL(k_extend<S>, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), q.o, q.d, count, c->dHits,
-                     cursor);
+  hipLaunchKernelGGL(k_extend<S>, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), q.o, q.d,
+                     QueueFill{fill, c->capPart}, c->dHits, cursor);
   return 0;
 }
 
 // Stack depth of the kernel instance: the smallest that holds the uploaded trees.
-int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* count, uint32_t* cursor, size_t maxItems) {
-  if (c->stackNeed <= 16) return launch_extend<16>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 20) return launch_extend<20>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 24) return launch_extend<24>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 32) return launch_extend<32>(c, q, count, cursor, maxItems);
-  if (c->stackNeed <= 48) return launch_extend<48>(c, q, count, cursor, maxItems);
-  return launch_extend<64>(c, q, count, cursor, maxItems);
+// `fill`: the queue's set of fill counts, `cursor`: a zeroed set of cursors
+int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* cursor, size_t maxItems) {
+  if (c->stackNeed <= 16) return launch_extend<16>(c, q, fill, cursor, maxItems);
+  if (c->stackNeed <= 20) return launch_extend<20>(c, q, fill, cursor, maxItems);
+  if (c->stackNeed <= 24) return launch_extend<24>(c, q, fill, cursor, maxItems);
+  if (c->stackNeed <= 32) return launch_extend<32>(c, q, fill, cursor, maxItems);
+  if (c->stackNeed <= 48) return launch_extend<48>(c, q, fill, cursor, maxItems);
+  return launch_extend<64>(c, q, fill, cursor, maxItems);
 }
+
+// The set of fill counts of bounce b's queue / the set of ray cursors for bounce b's launch.
+uint32_t* fills_of(const lpt_ctx* c, uint32_t b) { return c->dCounts + (size_t)b * kCursorWords; }
+uint32_t* cursors_of(const lpt_ctx* c, uint32_t b) { return c->dCounts + ((size_t)c->poolBounces + b) * kCursorWords; }
 
 // Camera rays of `frames` frames into queue `q` (as k_generate leaves them) and their closest hits into c->dHits.
 void launch_primary(lpt_ctx* c, const Queue& q, int frames) {
@@ -1021,17 +1058,18 @@ void launch_primary(lpt_ctx* c, const Queue& q, int frames) {
                      PrimaryQueue{q.o, q.d, q.m}, c->dHits);
 }
 
-// The whole first segment of `frames` frames: paths that go on land in queue `out`, count at c->dCounts[1].
+// The whole first segment of `frames` frames: paths that go on land in queue `out`, fill counts of bounce 1.
 void launch_primary_shade(lpt_ctx* c, const Queue& out, int frames) {
   const size_t paths = (size_t)frames * c->part.nSlots;
   if (paths == 0 || c->nValid == 0) return;
   const DScene sc = device_scene(c);
   hipLaunchKernelGGL(k_primary_shade, dim3((unsigned)((paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sc.nodes,
-                     sc.tris, sc.otrav, sc, c->part, c->dUbos, (uint32_t)frames, out, c->dCounts + 1, c->dSamples,
+                     sc.tris, sc.otrav, sc, c->part, c->dUbos, (uint32_t)frames, out, fills_of(c, 1), c->capPart, c->dSamples,
                      (uint32_t)c->maxBounces, c->bsdfMode);
 }
 
-// Shading of bounce b: queue `in` with c->dHits -> queue `out`; counts at c->dCounts[b], [b+1].
+// Shading of bounce b: queue `in` with c->dHits -> queue `out`; fill counts of bounces b and b + 1.  The grid is
+// a multiple of the number of part queues (every workgroup shades one part).
 void launch_shade(lpt_ctx* c, const Queue& in, const Queue& out, uint32_t b, uint32_t nB, size_t paths) {
   static const int resident = [] {
     int n = 0;
@@ -1040,8 +1078,9 @@ void launch_shade(lpt_ctx* c, const Queue& in, const Queue& out, uint32_t b, uin
   }();
   static const int capPerCU = std::getenv("LPT_SHADE_BLOCKS_PER_CU") ? std::atoi(std::getenv("LPT_SHADE_BLOCKS_PER_CU")) : 0;
   const int perCU = capPerCU > 0 ? std::min(resident, capPerCU) : resident;
-  hipLaunchKernelGGL(k_shade, dim3(grid_for(c, paths, perCU)), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
-                     c->dCounts + b, out, c->dCounts + b + 1, c->dSamples, b, nB, c->bsdfMode);
+  const int grid = (grid_for(c, paths, perCU) + (int)kCursorRegions - 1) / (int)kCursorRegions * (int)kCursorRegions;
+  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), in, c->dHits,
+                     QueueFill{fills_of(c, b), c->capPart}, out, fills_of(c, b + 1), c->dSamples, b, nB, c->bsdfMode);
 }
 
 // `ubos` / `samples`: null = the context's pool (c->dUbos, c->dSamples)
@@ -1054,8 +1093,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorWords) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
-  uint32_t* cursors = c->dCounts + c->poolBounces;
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, 2 * kCursorWords * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   rc = stage_frames(c, ubos, frames, true);
   if (rc) return rc;
   if (c->nValid && !primary_packets())  // the packet kernel generates the camera rays itself
@@ -1078,15 +1116,15 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
       launch_primary(c, in, frames);
     } else {  // the k_extend launches are timed one by one (lpt_stats.extend_ms)
       LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-      dispatch_extend(c, in, c->dCounts + b, cursors + (size_t)b * kCursorWords, paths);
+      dispatch_extend(c, in, fills_of(c, b), cursors_of(c, b), paths);
       LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     }
     launch_shade(c, in, out, b, nB, paths);
   }
   if (tail < nB) {
     const Queue& q = c->queues[tail & 1];
-    dispatch_trace<true>(c, frames, cursors + (size_t)tail * kCursorWords,
-                         TraceQueue{q.o, q.d, q.m, c->dCounts + tail, tail, 0u});
+    dispatch_trace<true>(c, frames, cursors_of(c, tail),
+                         TraceQueue{q.o, q.d, q.m, QueueFill{fills_of(c, tail), c->capPart}, tail, 0u});
   }
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
@@ -1136,7 +1174,7 @@ int render_batch_persistent(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   rc = ensure_events(c, c->evUsed + 2);
   if (rc) return rc;
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-  dispatch_trace<false>(c, frames, c->dCounts, TraceQueue{nullptr, nullptr, nullptr, nullptr, 0u, 1u});
+  dispatch_trace<false>(c, frames, c->dCounts, TraceQueue{nullptr, nullptr, nullptr, QueueFill{nullptr, 0u}, 0u, 1u});
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
@@ -1152,8 +1190,8 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, (1 + kCursorWords) * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
-  uint32_t* cursors = c->dCounts + c->poolBounces;  // poolBounces >= 2: regions of bounce 0 and bounce 1 exist
+  // (poolBounces >= 2: the sets of bounce 0 and bounce 1 exist)
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, 2 * kCursorWords * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   rc = stage_frames(c, ubos, frames, true);
   if (rc) return rc;
   rc = ensure_events(c, c->evUsed + 2);
@@ -1169,13 +1207,14 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
     } else {
       hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                          (uint32_t)frames, q0, c->dValidBefore, c->nValid);
-      dispatch_extend(c, q0, c->dCounts, cursors, paths);
+      dispatch_extend(c, q0, fills_of(c, 0), cursors_of(c, 0), paths);
       launch_shade(c, q0, q1, 0, nB, paths);
     }
   }
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   if (nB > 1 && c->nValid)
-    dispatch_trace<true>(c, frames, cursors + kCursorWords, TraceQueue{q1.o, q1.d, q1.m, c->dCounts + 1, 1u, 1u});
+    dispatch_trace<true>(c, frames, cursors_of(c, 1),
+                         TraceQueue{q1.o, q1.d, q1.m, QueueFill{fills_of(c, 1), c->capPart}, 1u, 1u});
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
@@ -1737,7 +1776,7 @@ int lpt_render_frame_static(lpt_ctx* c, const lpt_ubo* ubo) {
   LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
   hipLaunchKernelGGL(k_store_ubo, dim3(1), dim3(64), 0, c->stream, *ubo, dUbo);
   if (c->nValid)
-    dispatch_trace<false>(c, 1, cursor, TraceQueue{nullptr, nullptr, nullptr, nullptr, 0u, 1u}, dUbo, samples);
+    dispatch_trace<false>(c, 1, cursor, TraceQueue{nullptr, nullptr, nullptr, QueueFill{nullptr, 0u}, 0u, 1u}, dUbo, samples);
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, dUbo, 1u,
                      samples, c->dAccum);
   LPT_HIP(c, hipGetLastError());

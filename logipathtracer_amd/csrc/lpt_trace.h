@@ -53,14 +53,14 @@ struct TraceShared {
   uint32_t stack[S * BLOCK];
 };
 
-// Where the paths of a launch come from when QUEUED: entries [0, *count) of a path queue (origin | path-id
-// word, direction | rng.x, throughput | rng.y) written by the shading kernel of bounce `bounce` - 1; the
-// paths go on from bounce `bounce`.
+// Where the paths of a launch come from when QUEUED: the part queues (QueueFill, lpt_extend.h) of a path queue
+// (origin | path-id word, direction | rng.x, throughput | rng.y) written by the shading kernel of bounce
+// `bounce` - 1; the paths go on from bounce `bounce`.
 struct TraceQueue {
   const float4* o;
   const float4* d;
   const float4* m;
-  const uint32_t* count;
+  QueueFill fill;
   uint32_t bounce;
   uint32_t timed;  // this launch is the one whose time the statistics report: its segments go to totals[16] too
 };
@@ -77,8 +77,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
                                                  uint32_t roundLimit) {
   uint32_t* stk = &sh.stack[threadIdx.x];
   const uint32_t lane = threadIdx.x & 63u;
-  // path ids of the batch (frame-major, slot-minor), or the queue's entries
-  const uint32_t n = QUEUED ? *src.count : nFrames * P.nSlots;
+  // path ids of the batch (frame-major, slot-minor) cut into equal regions, or the queue's parts
+  const uint32_t n = QUEUED ? 0u : nFrames * P.nSlots;
 
   // wave-uniform chunk of path ids [chunkNext, chunkEnd)
   uint32_t chunkNext = 0, chunkEnd = 0;
@@ -224,13 +224,17 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
       if (nN > 0 && (nN >= (QUEUED ? LPT_NEW_MIN_QUEUED : LPT_NEW_MIN) || !othersActive)) {
         LPT_STAT(4, nN);
         while (!exhausted && chunkNext >= chunkEnd) {
-          const uint32_t lo = region * regionSize, hi = min(lo + regionSize, n);
-          uint32_t b = 0;
-          if (lane == 0) b = atomicAdd(&cursor[region * kCursorStride], kFetchChunk);
-          b = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
-          if (lo < hi && b < hi) {
-            chunkNext = b;
-            chunkEnd = min(b + kFetchChunk, hi);
+          // region = [lo, lo + size): a part of the queue, or an equal share of the batch's path ids
+          const uint32_t lo = QUEUED ? region * src.fill.capPart : min(n, region * regionSize);
+          const uint32_t size = QUEUED ? part_fill(src.fill, region) : min(regionSize, n - lo);
+          uint32_t b = size;
+          if (size != 0u) {
+            if (lane == 0) b = atomicAdd(&cursor[region * kCursorStride], kFetchChunk);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)b, 0));
+          }
+          if (b < size) {
+            chunkNext = lo + b;
+            chunkEnd = lo + min(b + kFetchChunk, size);
           } else {
             region = (region + 1u) % kCursorRegions;
             if (++regionsTried >= kCursorRegions) exhausted = true;
