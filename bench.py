@@ -107,7 +107,7 @@ def range_means(upto_hi, upto_lo):
     return out
 
 
-def roofline(args, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext_launches, props):
+def roofline(args, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext_launches, props, timed_bounces):
     """Roofline block of the dominant kernel: k_extend (wavefront organisation) or k_trace.
 
     What bounds these kernels is the vector L1: every search step is a per-lane gather of one small record
@@ -122,14 +122,9 @@ def roofline(args, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext
     chip (profiles/r02_gather_peak.json, tools/gather_peak.hip), the algorithmic bytes in interchange terms
     (48 B per node fetched + 36 B per triangle + state), and HBM traffic from the committed PMC passes."""
     kernel = {0: "k_extend", 2: "k_trace", 4: "k_trace"}.get(used_pipeline, "k_megakernel")
-    packets = used_pipeline in (0, 4) and os.environ.get("LPT_PRIMARY_PACKETS", "1") != "0"
-    # the bounces whose segments the timed kernel traces: [lo, hi)
-    lo = 1 if packets else 0
-    hi = args.bounces
-    if used_pipeline == 0:  # the wavefront organisation hands the late bounces to one persistent launch
-        tail = int(os.environ.get("LPT_WAVEFRONT_TAIL", "4"))
-        if 1 <= tail < args.bounces:
-            hi = tail
+    # the bounces whose segments the timed kernel traces: [lo, hi) (lpt_stats; the wavefront organisation hands
+    # the late bounces to one persistent launch where the queues become short)
+    lo, hi = timed_bounces
     upto_hi = counters if hi == args.bounces else traversal_counters(scene, ubos, args.width, args.height, hi)
     upto_lo = traversal_counters(scene, ubos, args.width, args.height, lo) if lo > 0 else None
     rm = range_means(upto_hi, upto_lo)
@@ -289,6 +284,7 @@ def main():
         ext_launches += st.extend_launches
         dev_ms += st.device_ms
         used_pipeline = st.pipeline
+        timed_bounces = (int(st.timed_bounce_lo), int(st.timed_bounce_hi))
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -361,7 +357,7 @@ def main():
         result["cpu_baseline"] = cpu
         result["kernel_segments"] = float(kernel_seg_total)  # segments traced by the launches extend_ms times
         result["roofline"] = roofline(args, scene, ubos, counters, used_pipeline, kernel_seg_total, ext_ms, ext_launches,
-                                      torch.cuda.get_device_properties(device_index)) if counters and ext_ms > 0 else None
+                                      torch.cuda.get_device_properties(device_index), timed_bounces) if counters and ext_ms > 0 else None
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

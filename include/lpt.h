@@ -94,7 +94,7 @@ typedef enum lpt_status {
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
 /* Kernel organisation; all produce identical pixels.
- * AUTO (default): HYBRID; WAVEFRONT for batches of about 100 Mi paths and more; PERSISTENT when
+ * AUTO (default): HYBRID; WAVEFRONT for batches of 24 Mi paths and more; PERSISTENT when
  *            the ray queues do not fit in device memory.
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (128 bytes of
  *            queues per path in flight); the first segment runs in the packet kernel, bounces
@@ -130,6 +130,8 @@ typedef struct lpt_stats {
   uint32_t extend_launches;
   uint32_t pipeline;      /* organisation the call ran with (what LPT_PIPELINE_AUTO resolved to) */
   uint64_t kernel_segments; /* the segments traced by the launches that extend_ms times */
+  uint32_t timed_bounce_lo; /* those launches traced the segments of bounces [lo, hi) (of the call's last batch; */
+  uint32_t timed_bounce_hi; /*  the wavefront organisation chooses per batch where its persistent launch takes over) */
 } lpt_stats;
 
 /* ---- context ---------------------------------------------------------------- */

@@ -45,7 +45,6 @@ static_assert(offsetof(lpt_ubo, seed) == 80 && offsetof(lpt_ubo, reset) == 88, "
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kTotalsWords = 24;  // [0] paths, [1] segments, [2..15] analysis builds, [16] segments of timed launches
 
 // Path queue, Structure of Arrays; slot i of each array belongs to one path.
 // The radiance a path has gathered does not travel with it: it lives in samples[path id], which
@@ -471,23 +470,34 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Partition P, const lpt_ub
   }
 }
 
-// totals[0] += paths started, totals[1] += ray segments traced (queue fills per bounce), totals[16] += those
+// totals[kTotPaths] += paths started, totals[kTotSegments] += ray segments traced (queue fills per bounce), totals[kTotTimed] += those
 // of the bounces from `timedFrom` on (the ones whose extend launches are timed).  `fills`: one set of fill
 // counts per bounce.
+// `report` (may be null): words in host memory that receive the batch's queue fills, for the host to choose the
+// next batch's hand-over bounce by: [b] = fill of bounce b for b <= min(nBounces, kReportBounces - 1) (the queue of
+// bounce nBounces is the one handed to the persistent launch, if any), [kReportBounces] = nBounces,
+// [kReportBounces + 1] = paths started.
+constexpr uint32_t kReportBounces = 64, kReportWords = kReportBounces + 2;
 __global__ void k_tally(const uint32_t* __restrict__ fills, uint32_t nBounces, uint32_t timedFrom,
-                        unsigned long long* totals) {
+                        unsigned long long* totals, uint32_t haveNext, uint32_t* report) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long seg = 0, timed = 0, first = 0;
-    for (uint32_t b = 0; b < nBounces; ++b) {
+    for (uint32_t b = 0; b < nBounces + haveNext; ++b) {
       unsigned long long n = 0;
       for (uint32_t r = 0; r < kCursorRegions; ++r) n += fills[b * kCursorWords + r * kCursorStride];
+      if (report && b < kReportBounces) report[b] = (uint32_t)n;
+      if (b >= nBounces) break;  // the queue handed on: reported, but its segments are counted by the launch that takes it
       seg += n;
       if (b >= timedFrom) timed += n;
       if (b == 0) first = n;
     }
-    totals[0] += first;
-    totals[1] += seg;
-    totals[16] += timed;
+    if (report) {
+      report[kReportBounces + 1] = (uint32_t)first;
+      report[kReportBounces] = nBounces;
+    }
+    totals[kTotPaths] += first;
+    totals[kTotSegments] += seg;
+    totals[kTotTimed] += timed;
   }
 }
 
@@ -543,8 +553,8 @@ __global__ __launch_bounds__(kBlock) void k_megakernel(DScene sc, Partition P, l
     started += (uint32_t)__shfl_down((int)started, off);
   }
   if ((threadIdx.x & 63) == 0 && started) {
-    atomicAdd(&totals[0], (unsigned long long)started);
-    atomicAdd(&totals[1], (unsigned long long)segments);
+    atomicAdd(&totals[kTotPaths], (unsigned long long)started);
+    atomicAdd(&totals[kTotSegments], (unsigned long long)segments);
   }
 }
 
@@ -714,10 +724,11 @@ struct lpt_ctx {
   bool stagingBusy[2] = {false, false};
   int stagingNext = 0;
   int ubosCap = 0;
-  unsigned long long* dTotals = nullptr;  // [0] paths, [1] segments
+  unsigned long long* dTotals = nullptr;  // kTotalsWords words: paths, segments, segments of timed launches (lpt_trace.h)
   // Words the kernels raise when they give up: pinned host memory the device writes through its mapped
   // address, so the host reads them after a stream synchronisation without a copy.
   // [0]: a persistent launch reached its round limit with paths still in flight.
+  // [4 ..]: the queue fills the last finished wavefront batch reported (k_tally), read without waiting.
   volatile uint32_t* hFlags = nullptr;
   uint32_t* dFlags = nullptr;
   uint32_t traceRoundLimit = LPT_TRACE_ROUND_LIMIT;
@@ -728,6 +739,7 @@ struct lpt_ctx {
   std::vector<hipEvent_t> evPool;
   size_t evUsed = 0;
   uint64_t lastFrames = 0;
+  uint32_t timedLo = 0, timedHi = 0;  // bounces whose segments the timed launches of the last batch traced
   bool haveTiming = false;
 };
 
@@ -1101,10 +1113,36 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
                        (uint32_t)frames, c->queues[0], c->dValidBefore, c->nValid);
   rc = ensure_events(c, c->evUsed + 2 * (size_t)nB);
   if (rc) return rc;
-  // From bounce `tail` on the queues are short (Russian roulette thins them out from bounce 3) and a launch
-  // per bounce costs more in tails than it does work: one persistent launch finishes those paths.
-  static const uint32_t tailFrom = std::getenv("LPT_WAVEFRONT_TAIL") ? (uint32_t)std::atoi(std::getenv("LPT_WAVEFRONT_TAIL")) : 4u;
-  const uint32_t tail = tailFrom >= 1u && tailFrom < nB ? tailFrom : nB;
+  // From bounce `tail` on one persistent launch finishes the paths: once a queue has become short (Russian
+  // roulette thins the paths out from bounce 3; in an open scene most rays leave) a launch pair per bounce costs
+  // more in start-up and tails than it does work.  Where that happens depends on the scene, so the choice follows
+  // the queue fills the last finished batch reported: the first bounce whose queue held fewer than kShortQueue
+  // rays (scaled to this batch's size); without a report, or when even the last reported queue was long, no
+  // hand-over at all.  Measured, 1080p: Cornell box, 64 frames, 3.3 M rays in bounce 7: a launch pair per bounce
+  // for every bounce +2.2 % over handing over at bounce 4; a scene whose queues drop to 66 k rays at bounce 5:
+  // handing over there +1 % over no hand-over.  LPT_WAVEFRONT_TAIL=b fixes the bounce.
+  static const int tailFixed = std::getenv("LPT_WAVEFRONT_TAIL") ? std::atoi(std::getenv("LPT_WAVEFRONT_TAIL")) : 0;
+  uint32_t tail = nB;
+  if (tailFixed >= 1) {
+    tail = std::min<uint32_t>((uint32_t)tailFixed, nB);
+  } else {
+    const volatile uint32_t* rep = c->hFlags + 4;
+    const uint32_t repBounces = rep[kReportBounces], repPaths = rep[kReportBounces + 1];
+    if (repBounces >= 1u && repPaths > 0u) {
+      constexpr double kShortQueue = 1024.0 * 1024.0;
+      const double scale = (double)paths / (double)repPaths;
+      const uint32_t known = std::min(std::min(repBounces, kReportBounces - 1u), nB - 1u);  // fills [0, known] are reported
+      for (uint32_t b = 1; b <= known; ++b)
+        if ((double)rep[b] * scale < kShortQueue) {
+          tail = b;
+          break;
+        }
+      // every reported queue was long: if the report ended at a hand-over, try one bounce further
+      if (tail == nB && repBounces < nB) tail = std::min(nB, known + 1u);
+    }
+  }
+  c->timedLo = primary_packets() ? 1u : 0u;
+  c->timedHi = tail;
   for (uint32_t b = 0; b < tail; ++b) {
     const Queue& in = c->queues[b & 1];
     const Queue& out = c->queues[(b + 1) & 1];
@@ -1129,7 +1167,8 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
   // segments of the bounces run here; the persistent launch has added those it traced
-  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, tail, primary_packets() ? 1u : 0u, c->dTotals);
+  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, tail, primary_packets() ? 1u : 0u, c->dTotals,
+                     tail < nB ? 1u : 0u, c->dFlags + 4);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -1173,6 +1212,8 @@ int render_batch_persistent(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, kCursorWords * sizeof(uint32_t), c->stream));
   rc = ensure_events(c, c->evUsed + 2);
   if (rc) return rc;
+  c->timedLo = 0u;
+  c->timedHi = (uint32_t)c->maxBounces;
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   dispatch_trace<false>(c, frames, c->dCounts, TraceQueue{nullptr, nullptr, nullptr, QueueFill{nullptr, 0u}, 0u, 1u});
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
@@ -1211,6 +1252,8 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
       launch_shade(c, q0, q1, 0, nB, paths);
     }
   }
+  c->timedLo = 1u;
+  c->timedHi = nB;
   LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
   if (nB > 1 && c->nValid)
     dispatch_trace<true>(c, frames, cursors_of(c, 1),
@@ -1219,7 +1262,7 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
   // camera paths and their segments; the persistent launch has added the segments it traced
-  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, 1u, 1u, c->dTotals);
+  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, 1u, 1u, c->dTotals, 0u, (uint32_t*)nullptr);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -1341,10 +1384,10 @@ int lpt_create(int device, lpt_ctx** out) {
   if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&c->dStatic), HIP_SYMBOL(scratch))) != hipSuccess)
     return bail("hipGetSymbolAddress(scratch)", e);
   void* flags = nullptr;
-  if ((e = hipHostMalloc(&flags, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+  if ((e = hipHostMalloc(&flags, (4 + kReportWords) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
     return bail("hipHostMalloc", e);
   c->hFlags = static_cast<volatile uint32_t*>(flags);
-  for (int k = 0; k < 4; ++k) c->hFlags[k] = 0u;
+  for (uint32_t k = 0; k < 4 + kReportWords; ++k) c->hFlags[k] = 0u;
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dFlags), flags, 0)) != hipSuccess)
     return bail("hipHostGetDevicePointer", e);
   *out = c;
@@ -1715,16 +1758,15 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     fif = std::max(1, std::min<int>(fif, (int)(0x7FFFFFFFu / std::max<uint32_t>(c->part.nSlots, 1u))));
     // AUTO.  The first segment of every path runs in the packet kernel whenever there are queues.  After that:
     //  - HYBRID (one persistent launch for everything beyond the first segment) has no per-bounce launches
-    //    and tails: best for small and medium batches (Cornell box 1080p, one frame: 3.4x the wavefront
-    //    kernels);
-    //  - WAVEFRONT (one extend and one shade launch per bounce up to bounce 3, the thinned-out rest in one
-    //    persistent launch) keeps seven waves per SIMD in the search and full waves in shading: ahead once
-    //    a batch is large enough to amortise its launches, from about 100 Mi paths (Cornell box: +4 % at
-    //    128 Mi paths, +8 % at 256 Mi; a 400 k-triangle scene: +1 %);
+    //    and tails: best for small batches (Cornell box 1080p, one frame: 3.4x the wavefront kernels);
+    //  - WAVEFRONT (one extend and one shade launch per bounce while the queues are long, the rest in one
+    //    persistent launch) keeps seven waves per SIMD in the search and full waves in shading: ahead once a
+    //    batch amortises its launches.  Cornell box 1080p, G segments/s by frames per batch (wavefront / hybrid):
+    //    4: 5.85 / 6.34, 8: 7.06 / 7.22, 16: 8.09 / 7.65, 32: 8.73 / 7.90, 64: 9.10 / 8.02, 128: 9.29 / 8.08;
     //  - PERSISTENT (no queues, 16 instead of 64 / 128 bytes per path in flight) when the queues do not fit.
     c->activePipeline = c->pipeline;
     if (c->pipeline == LPT_PIPELINE_AUTO) {
-      const bool largeBatch = (double)fif * c->part.nSlots >= 96.0 * 1024 * 1024;
+      const bool largeBatch = (double)fif * c->part.nSlots >= 24.0 * 1024 * 1024;
       c->activePipeline = largeBatch ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_HYBRID;
     }
     rc = ensure_pool(c, fif);
@@ -1833,9 +1875,9 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
       std::fprintf(stderr, "trace wave time %-8s %5.1f %%\n", names[k], all > 0 ? 100.0 * (double)t[12 + k] / all : 0.0);
   }
 #endif
-  out->paths = totals[0];
-  out->segments = totals[1];
-  out->kernel_segments = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? totals[1] : totals[16];
+  out->paths = totals[kTotPaths];
+  out->segments = totals[kTotSegments];
+  out->kernel_segments = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? totals[kTotSegments] : totals[kTotTimed];
   out->frames = c->lastFrames;
   float ms = 0.0f;
   LPT_HIP(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
@@ -1848,6 +1890,8 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   out->extend_ms = ext;
   out->extend_launches = (uint32_t)(c->evUsed / 2);
   out->pipeline = (uint32_t)c->activePipeline;
+  out->timed_bounce_lo = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? 0u : c->timedLo;
+  out->timed_bounce_hi = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? (uint32_t)c->maxBounces : c->timedHi;
   return LPT_OK;
 }
 

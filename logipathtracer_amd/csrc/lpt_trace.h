@@ -46,6 +46,9 @@ namespace lpt {
 #ifndef LPT_TRACE_ROUND_LIMIT
 #define LPT_TRACE_ROUND_LIMIT (1u << 24)
 #endif
+// Words of the totals array the kernels add to, one cache line apart (every wave of a launch adds to them when
+// it ends, and atomics on one line are carried out one after the other); [2..15] belong to the analysis builds.
+constexpr int kTotPaths = 0, kTotTimed = 16, kTotSegments = 32, kTotalsWords = 48;
 constexpr int kTsNew = 0, kTsInner = 1, kTsTri = 2, kTsObj = 3, kTsShade = 4, kTsWalk = 5, kTsDone = 6;
 
 template <int S, int BLOCK>
@@ -62,10 +65,10 @@ struct TraceQueue {
   const float4* m;
   QueueFill fill;
   uint32_t bounce;
-  uint32_t timed;  // this launch is the one whose time the statistics report: its segments go to totals[16] too
+  uint32_t timed;  // this launch is the one whose time the statistics report: its segments go to totals[kTotTimed] too
 };
 
-// `cursor` holds one zeroed set of cursors (kCursorWords words); `totals[0]` counts paths, `totals[1]` ray segments, `totals[16]`
+// `cursor` holds one zeroed set of cursors (kCursorWords words); `totals[kTotPaths]` counts paths, `totals[kTotSegments]` ray segments, `totals[kTotTimed]`
 // the segments of timed launches
 // (QUEUED: only the segments traced here are added).
 template <int S, int BLOCK, bool QUEUED>
@@ -435,9 +438,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     nPaths += (uint32_t)__shfl_down((int)nPaths, off);
   }
   if (lane == 0 && nPaths) {
-    if (!QUEUED) atomicAdd(&totals[0], (unsigned long long)nPaths);
-    atomicAdd(&totals[1], (unsigned long long)nSegments);
-    if (src.timed) atomicAdd(&totals[16], (unsigned long long)nSegments);
+    if (!QUEUED) atomicAdd(&totals[kTotPaths], (unsigned long long)nPaths);
+    atomicAdd(&totals[kTotSegments], (unsigned long long)nSegments);
+    if (src.timed) atomicAdd(&totals[kTotTimed], (unsigned long long)nSegments);
   }
 #ifdef LPT_TRACE_STATS
   if (lane == 0)

@@ -342,6 +342,10 @@ def test_persistent_launch_out_of_rounds_is_reported(cornell, cornell_oracle):
         dev.resize(w, h)
         for pipeline in (L.PIPELINE_PERSISTENT, L.PIPELINE_HYBRID, L.PIPELINE_WAVEFRONT):
             dev.set_options(bounces, L.BSDF_HEITZ, pipeline, 0)
+            # (the wavefront organisation hands its short queues to a persistent launch once a finished batch
+            # has reported how long they are: these small ones from bounce 1 on)
+            dev.render_frames(ubos)
+            dev.synchronize()
             dev.debug_set_trace_round_limit(16)
             dev.render_frames(ubos)
             with pytest.raises(L.LptError) as e:
