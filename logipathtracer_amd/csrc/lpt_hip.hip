@@ -973,6 +973,7 @@ int ensure_pool(lpt_ctx* c, int frames) {
   }
   if (c->maxBounces + 1 > c->poolBounces) {
     dfree(c->dCounts);
+    c->poolBounces = 0;  // stays 0 if the allocation fails: the next call tries again instead of using a null array
     LPT_HIP(c, hipMalloc(&c->dCounts, 2 * kCursorWords * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
     c->poolBounces = c->maxBounces + 1;
   }

@@ -469,3 +469,115 @@ def write_textured_cornell(path):
     g.node("Camera", camera=cam, translation=(6, 1, 0), rotation=(0, s, 0, s))
     g.write(path)
     return 14 + len(bi) // 3 + len(sf) // 3
+
+
+def _look_at_quat(eye, target):
+    """Rotation (x, y, z, w) of a glTF camera node at `eye` that looks at `target` (cameras look down -z, +y up)."""
+    f = np.asarray(target, np.float64) - np.asarray(eye, np.float64)
+    f /= max(np.linalg.norm(f), 1e-12)
+    up = np.array([0.0, 1.0, 0.0]) if abs(f[1]) < 0.99 else np.array([1.0, 0.0, 0.0])
+    r = np.cross(f, up)
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    m = np.stack([r, u, -f], axis=1)  # columns: camera x, y, z axes in the world
+    w = np.sqrt(max(0.0, 1.0 + m[0, 0] + m[1, 1] + m[2, 2])) / 2.0
+    if w > 1e-6:
+        q = [(m[2, 1] - m[1, 2]) / (4 * w), (m[0, 2] - m[2, 0]) / (4 * w), (m[1, 0] - m[0, 1]) / (4 * w), w]
+    else:  # half-turn: take the axis from the largest diagonal entry
+        k = int(np.argmax([m[0, 0], m[1, 1], m[2, 2]]))
+        a = np.zeros(3)
+        a[k] = np.sqrt(max(0.0, (m[k, k] + 1.0) / 2.0))
+        for j in range(3):
+            if j != k:
+                a[j] = m[k, j] / (2.0 * a[k]) if a[k] else 0.0
+        q = [a[0], a[1], a[2], 0.0]
+    return tuple(float(x) for x in q)
+
+
+def write_random_scene(path, seed, hard=False):
+    """A scene drawn from `seed`, for parity fuzzing: 3-12 objects (boxes, spheres, quads, triangle soups with
+    zero-area and sliver triangles) under random rotations and non-uniform, now and then mirrored scales, materials
+    over the whole parameter range (roughness 0 and 1, metallic 0 / 1 / in between, transmission with ior below and
+    above 1, emitters), normals that need not fit the geometry, sometimes a closed emissive shell around everything,
+    and a camera that may sit inside an object.  `hard` adds what produces infinities and NaNs: zero-length normals,
+    scales of exactly zero along one axis (singular world matrices) and a camera on a coordinate axis looking along it
+    (ray directions with zero components).  Returns the number of triangles."""
+    rng = np.random.default_rng(0x51DE0000 + int(seed) + (0x10000 if hard else 0))
+    g = _GltfBuilder()
+
+    def rand_material(k):
+        base = tuple(float(x) for x in rng.uniform(0.02, 1.0, 3)) + (1.0,)
+        metallic = float(rng.choice([0.0, 1.0, rng.uniform(0, 1)]))
+        roughness = float(rng.choice([0.0, 0.001, 1.0, rng.uniform(0, 1), rng.uniform(0, 0.2)]))
+        emissive = tuple(float(x) for x in rng.uniform(0, 6, 3)) if rng.random() < 0.2 else None
+        if rng.random() < 0.3:
+            return g.material(f"M{k}", base, metallic, roughness, emissive=emissive,
+                              transmission=float(rng.choice([1.0, 0.98, rng.uniform(0, 1)])),
+                              ior=float(rng.choice([1.0, 1.33, 1.5, 1.8, 0.8])))
+        return g.material(f"M{k}", base, metallic, roughness, emissive=emissive)
+
+    def soup(n):
+        c = rng.uniform(-1, 1, (n, 1, 3))
+        p = c + rng.normal(scale=rng.choice([0.05, 0.3, 1.0]), size=(n, 3, 3))
+        kind = rng.random(n)
+        p[kind < 0.05, 1] = p[kind < 0.05, 0]                       # two equal corners
+        p[(kind >= 0.05) & (kind < 0.08)] = c[(kind >= 0.05) & (kind < 0.08)]  # a point
+        sl = (kind >= 0.08) & (kind < 0.12)                          # slivers: third corner on the first edge
+        p[sl, 2] = 0.5 * (p[sl, 0] + p[sl, 1])
+        return p.reshape(-1, 3).astype(np.float32)
+
+    tris = 0
+    n_obj = int(rng.integers(3, 13))
+    for k in range(n_obj):
+        mat = rand_material(k)
+        shape = rng.choice(["box", "sphere", "quad", "soup", "soup"])
+        if shape == "box":
+            pos, nrm, idx = _box()
+        elif shape == "sphere":
+            pos, idx = _icosphere(int(rng.integers(0, 3)))
+            nrm = pos.copy()
+        elif shape == "quad":
+            pos = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+            nrm = np.tile([0, 1, 0], (4, 1)).astype(np.float32)
+            idx = np.array([0, 2, 1, 0, 3, 2], np.uint32)
+        else:
+            pos = soup(int(rng.integers(4, 200)))
+            e1, e2 = pos[1::3] - pos[0::3], pos[2::3] - pos[0::3]
+            fn = np.cross(e1, e2)
+            ln = np.linalg.norm(fn, axis=1, keepdims=True)
+            fn = np.where(ln > 1e-20, fn / np.maximum(ln, 1e-20), [[0.0, 1.0, 0.0]])
+            nrm = np.repeat(fn, 3, axis=0).astype(np.float32)
+            idx = np.arange(len(pos), dtype=np.uint32)
+        style = rng.random()
+        if style < 0.25:    # smooth-looking normals that do not fit the faces
+            nrm = rng.normal(size=nrm.shape)
+            nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+        elif style < 0.35:  # not unit length
+            nrm = (nrm * rng.uniform(0.1, 5.0, (len(nrm), 1))).astype(np.float32)
+        scale = rng.uniform(0.15, 2.0, 3) * rng.choice([1.0, 1.0, 1.0, -1.0], 3)
+        if rng.random() < 0.15:
+            scale[int(rng.integers(0, 3))] *= 0.01  # nearly flat
+        if hard and rng.random() < 0.2:
+            nrm = nrm.copy()
+            nrm[rng.random(len(nrm)) < 0.3] = 0.0
+        if hard and rng.random() < 0.15:
+            scale[int(rng.integers(0, 3))] = 0.0
+        g.node(f"Obj{k}", mesh=g.mesh(f"Mesh{k}", [(pos, nrm, idx, mat)]), translation=rng.uniform(-2.5, 2.5, 3),
+               rotation=_quat(rng), scale=scale)
+        tris += len(idx) // 3
+    if rng.random() < 0.5:  # closed emissive shell: paths run to their full depth
+        sv, sf = _icosphere(1)
+        shell = g.material("Shell", (0.5, 0.5, 0.5, 1), 0.0, 0.8, emissive=tuple(float(x) for x in rng.uniform(0.1, 1.0, 3))
+                           if rng.random() < 0.5 else None)
+        g.node("Shell", mesh=g.mesh("Shell", [(sv, -sv, sf.reshape(-1, 3)[:, ::-1].reshape(-1), shell)]), scale=(9, 9, 9))
+        tris += len(sf) // 3
+    eye = rng.uniform(-1, 1, 3) * rng.choice([0.5, 4.0, 6.0])
+    target = rng.uniform(-1, 1, 3)
+    if hard and rng.random() < 0.5:
+        axis = int(rng.integers(0, 3))
+        eye = np.zeros(3)
+        eye[axis] = float(rng.choice([-5.0, 5.0]))
+        target = np.zeros(3)
+    g.node("Camera", camera=g.camera(float(rng.uniform(0.3, 1.4))), translation=eye, rotation=_look_at_quat(eye, target))
+    g.write(path)
+    return tris
