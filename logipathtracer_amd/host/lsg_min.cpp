@@ -202,7 +202,6 @@ void readAccessor(const Doc& d, long long index, int comps, bool asIndex, std::v
   const long long ct = acc["componentType"].integer(0);
   const int nc = componentCount(acc["type"].string());
   if (nc != comps) throw std::runtime_error("glTF: accessor has unexpected element type");
-  const size_t count = (size_t)acc["count"].integer(0);
   const Value& bv = d.root["bufferViews"][(size_t)acc["bufferView"].integer(-1)];
   if (bv.isNull()) throw std::runtime_error("glTF: accessor without bufferView");
   const size_t bufIndex = (size_t)bv["buffer"].integer(0);
@@ -210,9 +209,16 @@ void readAccessor(const Doc& d, long long index, int comps, bool asIndex, std::v
   const std::string& buf = d.buffers[bufIndex];
   const size_t csz = (size_t)componentSize(ct);
   const size_t elem = csz * (size_t)nc;
-  const size_t stride = bv.has("byteStride") ? (size_t)bv["byteStride"].integer(0) : elem;
-  const size_t base = (size_t)bv["byteOffset"].integer(0) + (size_t)acc["byteOffset"].integer(0);
-  if (count && base + (count - 1) * stride + elem > buf.size()) throw std::runtime_error("glTF: accessor exceeds buffer");
+  // Counts, offsets and strides come from the file: negative or huge values must not wrap the range check.
+  const long long countLL = acc["count"].integer(0), strideLL = bv.has("byteStride") ? bv["byteStride"].integer(0) : (long long)elem;
+  const long long viewOff = bv["byteOffset"].integer(0), accOff = acc["byteOffset"].integer(0);
+  const long long size = (long long)buf.size();
+  if (countLL < 0 || viewOff < 0 || accOff < 0 || viewOff > size || accOff > size - viewOff)
+    throw std::runtime_error("glTF: accessor exceeds buffer");
+  if (strideLL < (long long)elem || strideLL > 4096) throw std::runtime_error("glTF: bufferView byteStride out of range");
+  const size_t count = (size_t)countLL, stride = (size_t)strideLL, base = (size_t)(viewOff + accOff);
+  if (count && (buf.size() - base < elem || (count - 1) > (buf.size() - base - elem) / stride))
+    throw std::runtime_error("glTF: accessor exceeds buffer");
   out.resize(count * (size_t)comps);
   for (size_t i = 0; i < count; ++i) {
     const char* p = buf.data() + base + i * stride;
@@ -273,8 +279,11 @@ Ref<Image> loadImage(Doc& d, size_t index) {
     if (bv.isNull()) throw std::runtime_error("glTF: image bufferView out of range");
     const size_t bi = (size_t)bv["buffer"].integer(0);
     if (bi >= d.buffers.size()) throw std::runtime_error("glTF: buffer index out of range");
-    const size_t off = (size_t)bv["byteOffset"].integer(0), len = (size_t)bv["byteLength"].integer(0);
-    if (off + len > d.buffers[bi].size()) throw std::runtime_error("glTF: image bufferView exceeds buffer");
+    const long long offLL = bv["byteOffset"].integer(0), lenLL = bv["byteLength"].integer(0);
+    const long long sizeLL = (long long)d.buffers[bi].size();
+    if (offLL < 0 || lenLL < 0 || offLL > sizeLL || lenLL > sizeLL - offLL)
+      throw std::runtime_error("glTF: image bufferView exceeds buffer");
+    const size_t off = (size_t)offLL, len = (size_t)lenLL;
     bytes = d.buffers[bi].substr(off, len);
   } else {
     throw std::runtime_error("glTF: image without uri or bufferView");
@@ -406,7 +415,12 @@ Ref<Geometry> loadPrimitive(const Doc& d, const Value& prim) {
   return g;
 }
 
-Ref<Object> buildNode(const Doc& d, size_t nodeIndex, const std::vector<Ref<Mesh>>& meshes, std::vector<int>& state) {
+// The scene graph is built, walked and destroyed recursively: hierarchies deeper than this are refused.
+constexpr int kMaxNodeDepth = 512;
+
+Ref<Object> buildNode(const Doc& d, size_t nodeIndex, const std::vector<Ref<Mesh>>& meshes, std::vector<int>& state,
+                      int depth = 0) {
+  if (depth > kMaxNodeDepth) throw std::runtime_error("glTF: node hierarchy is deeper than 512 levels");
   if (nodeIndex >= d.root["nodes"].size()) throw std::runtime_error("glTF: node index out of range");
   if (state[nodeIndex]) throw std::runtime_error("glTF: node hierarchy is not a tree");
   state[nodeIndex] = 1;
@@ -445,7 +459,7 @@ Ref<Object> buildNode(const Doc& d, size_t nodeIndex, const std::vector<Ref<Mesh
     }
   }
   const Value& ch = n["children"];
-  for (size_t i = 0; i < ch.size(); ++i) obj->addChild(buildNode(d, (size_t)ch[i].integer(-1), meshes, state));
+  for (size_t i = 0; i < ch.size(); ++i) obj->addChild(buildNode(d, (size_t)ch[i].integer(-1), meshes, state, depth + 1));
   return obj;
 }
 

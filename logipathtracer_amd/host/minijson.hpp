@@ -57,6 +57,8 @@ class Parser {
  private:
   const std::string& s_;
   size_t p_ = 0;
+  int depth_ = 0;  // open arrays and objects: bounded, so a file of nothing but '[' cannot exhaust the stack
+  static constexpr int kMaxDepth = 200;
 
   [[noreturn]] void fail(const char* what) const {
     throw std::runtime_error(std::string("JSON parse error at byte ") + std::to_string(p_) + ": " + what);
@@ -77,11 +79,13 @@ class Parser {
     if (p_ >= s_.size()) fail("unexpected end");
     char c = s_[p_];
     Value v;
+    if ((c == '{' || c == '[') && depth_ >= kMaxDepth) fail("nesting too deep");
     if (c == '{') {
       v.kind = Value::Object;
       ++p_;
       ws();
       if (p_ < s_.size() && s_[p_] == '}') { ++p_; return v; }
+      ++depth_;
       for (;;) {
         ws();
         if (p_ >= s_.size() || s_[p_] != '"') fail("expected member name");
@@ -95,11 +99,13 @@ class Parser {
         if (p_ < s_.size() && s_[p_] == '}') { ++p_; break; }
         fail("expected ',' or '}'");
       }
+      --depth_;
     } else if (c == '[') {
       v.kind = Value::Array;
       ++p_;
       ws();
       if (p_ < s_.size() && s_[p_] == ']') { ++p_; return v; }
+      ++depth_;
       for (;;) {
         v.arr.push_back(value());
         ws();
@@ -107,6 +113,7 @@ class Parser {
         if (p_ < s_.size() && s_[p_] == ']') { ++p_; break; }
         fail("expected ',' or ']'");
       }
+      --depth_;
     } else if (c == '"') {
       v.kind = Value::String;
       v.str = str();

@@ -135,3 +135,95 @@ def test_random_call_sequences_keep_the_image_equal_to_the_oracle(tmp_path, corn
         assert renders >= 8
     finally:
         dev.close()
+
+
+def _reachable_tree_is_safe(nodes, root, base, leaf_ok):
+    """Walks the binary tree at nodes[root] (child indices offset by `base`) the way a traversal would: False if it
+    would read outside the array, never end (a node among its own descendants) or meet a leaf `leaf_ok` refuses."""
+    n = len(nodes)
+    if root >= n:
+        return False
+    state = {}  # 1: on the current path, 2: finished
+    stack = [(root, False)]
+    while stack:
+        i, leaving = stack.pop()
+        if leaving:
+            state[i] = 2
+            continue
+        if state.get(i) == 1:
+            return False
+        if state.get(i) == 2:
+            continue
+        state[i] = 1
+        stack.append((i, True))
+        a, b = int(nodes["indices"][i][0]), int(nodes["indices"][i][1])
+        if nodes["isLeaf"][i]:
+            if not leaf_ok(a, b):
+                return False
+        else:
+            if base + a >= n or base + b >= n:
+                return False
+            stack += [(base + a, False), (base + b, False)]
+    return True
+
+
+@pytest.mark.gpu
+def test_upload_refuses_buffers_a_traversal_could_not_walk(device, cornell):
+    """Corrupts single fields of the interchange buffers (child indices, leaf ranges, leaf flags, offsets, texture
+    ids).  Whatever lpt_upload_scene accepts must be walkable: an independent host-side check of the reachable
+    trees agrees that no traversal would leave the arrays or loop.  Nothing is rendered from corrupted buffers."""
+    rng = np.random.default_rng(99)
+    n_obj, n_vert = len(cornell.objects), len(cornell.vertices)
+    values = [0, 1, 2, 3, 62, 63, 64, 65, 1000, n_obj - 1, n_obj, n_obj + 1, n_vert // 3, n_vert // 3 + 1, n_vert,
+              len(cornell.mesh_bvh) - 1, len(cornell.mesh_bvh), 2**24, 2**25, 2**31 - 1, 2**31, 2**32 - 1]
+    accepted = refused = 0
+    try:
+        for it in range(1500):
+            objects, obvh = cornell.objects.copy(), cornell.object_bvh.copy()
+            mbvh = cornell.mesh_bvh.copy()
+            for _ in range(int(rng.integers(1, 3))):
+                v = int(values[int(rng.integers(len(values)))]) if rng.random() < 0.8 else int(rng.integers(0, 2**32))
+                kind = int(rng.integers(0, 7))
+                if kind == 0:
+                    obvh["indices"][int(rng.integers(len(obvh)))][int(rng.integers(2))] = v
+                elif kind == 1:
+                    mbvh["indices"][int(rng.integers(len(mbvh)))][int(rng.integers(2))] = v
+                elif kind == 2:
+                    i = int(rng.integers(len(obvh)))
+                    obvh["isLeaf"][i] = 0 if obvh["isLeaf"][i] else int(rng.choice([1, 7, 2**31]))
+                elif kind == 3:
+                    i = int(rng.integers(len(mbvh)))
+                    mbvh["isLeaf"][i] = 0 if mbvh["isLeaf"][i] else 1
+                elif kind == 4:
+                    objects["bvhOffset"][int(rng.integers(n_obj))] = v
+                elif kind == 5:
+                    objects["verticesOffset"][int(rng.integers(n_obj))] = v
+                else:
+                    objects[str(rng.choice(["colorTexture", "emissionTexture", "metallicRoughnessTexture",
+                                            "transmissionTexture", "normalTexture"]))][int(rng.integers(n_obj))] = v
+            s = L.Scene.from_buffers(objects, obvh, cornell.vertices, mbvh, cornell.camera_world, cornell.fov_y)
+            try:
+                device.upload_scene(s)
+            except L.LptError:
+                refused += 1
+                continue
+            accepted += 1
+            ok = _reachable_tree_is_safe(obvh, 0, 0, lambda a, b: a <= b <= n_obj or b <= a)
+            entered = set()
+            stack = [0]
+            while stack and ok:  # objects the object tree's leaves name
+                i = stack.pop()
+                a, b = int(obvh["indices"][i][0]), int(obvh["indices"][i][1])
+                if obvh["isLeaf"][i]:
+                    entered.update(range(a, b))
+                else:
+                    stack += [a, b]
+            for o in sorted(entered):
+                off, vo = int(objects["bvhOffset"][o]), int(objects["verticesOffset"][o])
+                ok = ok and _reachable_tree_is_safe(mbvh, off, off, lambda a, b: b <= a or vo + 3 * b <= n_vert)
+                for t in ("colorTexture", "emissionTexture", "metallicRoughnessTexture", "transmissionTexture", "normalTexture"):
+                    ok = ok and int(objects[t][o]) == 0xFFFFFFFF  # no textures were uploaded
+            assert ok, f"mutation {it} was accepted but is not walkable"
+    finally:
+        device.upload_scene(cornell)  # the session's device goes on with a sound scene
+    assert refused > 300 and accepted > 50, (accepted, refused)

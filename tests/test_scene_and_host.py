@@ -133,6 +133,44 @@ def test_converter_rejects_dangling_textures_and_missing_files(tmp_path):
         L.Scene(str(tmp_path / "bad.gltf"))
 
 
+def test_malformed_files_are_refused_not_trusted(tmp_path):
+    """Offsets, counts and nesting come from the file: values that would wrap a range check or exhaust the
+    stack must end in an error message (found by mutating the Cornell file under AddressSanitizer)."""
+    import copy
+    import json
+    base = json.load(open(CORNELL))
+    (tmp_path / "cornell_box.bin").write_bytes(open(CORNELL.replace(".gltf", ".bin"), "rb").read())
+
+    def load(doc=None, raw=None):
+        p = tmp_path / "m.gltf"
+        p.write_text(raw if raw is not None else json.dumps(doc))
+        return L.Scene(str(p))
+
+    pos = base["meshes"][0]["primitives"][0]["attributes"]["POSITION"]
+    view = base["accessors"][pos]["bufferView"]
+    for field, where, value in (("byteOffset", "view", -1), ("byteOffset", "acc", -8), ("count", "acc", 2**31 - 1),
+                                ("count", "acc", 1e30), ("count", "acc", -3), ("byteStride", "view", 2**40),
+                                ("byteStride", "view", 1), ("byteOffset", "view", 2**62)):
+        g = copy.deepcopy(base)
+        (g["bufferViews"][view] if where == "view" else g["accessors"][pos])[field] = value
+        with pytest.raises(L.LptError, match="accessor exceeds buffer|byteStride out of range"):
+            load(g)
+    for raw in ("[" * 100000, '{"a":' * 100000):
+        with pytest.raises(L.LptError, match="nesting too deep"):
+            load(raw=raw)
+    g = copy.deepcopy(base)
+    first = len(g["nodes"])
+    g["nodes"] += [{"children": [first + i + 1]} for i in range(20000)] + [{}]
+    g["scenes"][0]["nodes"].append(first)
+    with pytest.raises(L.LptError, match="deeper than 512 levels"):
+        load(g)
+    g = copy.deepcopy(base)
+    g["nodes"][0]["children"] = [0]
+    with pytest.raises(L.LptError, match="not a tree"):
+        load(g)
+    assert len(load(base).objects) == 11  # the unmodified document still loads from the same place
+
+
 def test_frame_seeds_follow_glibc_rand():
     libc = C.CDLL(ctypes.util.find_library("c"))
     libc.rand.restype = C.c_int
