@@ -162,6 +162,112 @@ def test_rough_conductor_conserves_energy_on_white_and_darkens_with_order_on_col
     assert 0.05 < (orders > 1).mean() < 0.6
 
 
+def _ggx_lambda(w, alpha):
+    """Smith's Lambda of the GGX distribution for unit vectors w (..., 3) with w.z > 0."""
+    t2 = (w[..., 0] ** 2 + w[..., 1] ** 2) / np.maximum(w[..., 2] ** 2, 1e-300)
+    return 0.5 * (np.sqrt(1.0 + alpha * alpha * t2) - 1.0)
+
+
+@pytest.mark.parametrize("roughness,theta_deg", [(0.7, 50.0), (0.45, 20.0), (0.9, 70.0)])
+def test_first_scattering_order_of_the_rough_conductor_is_the_smith_ggx_brdf(roughness, theta_deg):
+    """Literature pin, independent of the shader's text: walks that leave the microsurface after ONE reflection are
+    distributed as the classical single-scattering microfacet model with the GGX distribution and Smith's
+    height-correlated masking-shadowing (Walter et al. 2007; Heitz 2014):
+        p1(wo) = D(h) / (4 cos(theta_i) (1 + Lambda(wi) + Lambda(wo))),   h = (wi + wo)/|wi + wo|,  alpha = roughness^2.
+    Orders are told apart by the weight (0.5 per reflection).  Binned over the hemisphere, 4.5 sigma per bin."""
+    alpha = roughness * roughness
+    th = np.radians(theta_deg)
+    wi = np.array([np.sin(th), 0.0, np.cos(th)])
+    n = 120000
+    dirs, wts = _sample_bsdf(O.K_METALLIC, tuple(wi), roughness, 1.5, n, base=(0.5, 0.5, 0.5))
+    order = np.round(np.log(wts[:, 0]) / np.log(0.5)).astype(int)
+    first = (order == 1) & (dirs[:, 2] > 0)
+    nz, nphi, sub = 6, 8, 48
+    zi = np.minimum((dirs[first, 2] * nz).astype(int), nz - 1)
+    ph = np.mod(np.arctan2(dirs[first, 1], dirs[first, 0]), 2 * np.pi)
+    pi_ = np.minimum((ph / (2 * np.pi) * nphi).astype(int), nphi - 1)
+    counts = np.zeros((nz, nphi))
+    np.add.at(counts, (zi, pi_), 1.0)
+    # the model, integrated over each bin (the solid-angle element is d(cos theta) d(phi): midpoint rule)
+    z = (np.arange(nz * sub) + 0.5) / (nz * sub)
+    phi = (np.arange(nphi * sub) + 0.5) / (nphi * sub) * 2 * np.pi
+    Z, P = np.meshgrid(z, phi, indexing="ij")
+    S = np.sqrt(1.0 - Z * Z)
+    wo = np.stack([S * np.cos(P), S * np.sin(P), Z], axis=-1)
+    h = wo + wi
+    h /= np.linalg.norm(h, axis=-1, keepdims=True)
+    D = alpha * alpha / (np.pi * ((alpha * alpha - 1.0) * h[..., 2] ** 2 + 1.0) ** 2)
+    p1 = D / (4.0 * wi[2] * (1.0 + _ggx_lambda(wi, alpha) + _ggx_lambda(wo, alpha)))
+    cell = (1.0 / (nz * sub)) * (2 * np.pi / (nphi * sub))
+    model = (p1 * cell).reshape(nz, sub, nphi, sub).sum(axis=(1, 3))
+    sigma = np.sqrt(model * (1.0 - model) / n)
+    err = np.abs(counts / n - model)
+    assert np.all(err <= 4.5 * sigma + 3e-4), (float((err / (sigma + 1e-12)).max()), counts.sum() / n, model.sum())
+    # and so is their share of all walks: the single-scattering albedo of the model
+    assert abs(first.mean() - model.sum()) <= 4.5 * np.sqrt(model.sum() * (1 - model.sum()) / n) + 1e-3
+
+
+@pytest.mark.parametrize("alpha,theta_deg", [(0.5, 60.0), (0.25, 30.0), (0.9, 85.0)])
+def test_visible_normals_follow_the_ggx_vndf(alpha, theta_deg):
+    """Normals drawn for a view direction wi are distributed as the distribution of VISIBLE normals (Heitz 2014):
+    D_wi(m) = G1(wi) max(0, wi.m) D(m) / cos(theta_i), G1 = 1 / (1 + Lambda(wi)) — which integrates to one."""
+    th = np.radians(theta_deg)
+    wi = np.array([np.sin(th), 0.0, np.cos(th)])
+    n = 60000
+    out = (C.c_float * 3)()
+    ms = np.empty((n, 3))
+    for i in range(n):
+        sd = O.Seed((i * 2246822519 + 99) & 0xFFFFFFFF, (i * 3266489917 + 7) & 0xFFFFFFFF)
+        O.lib.lpto_sample_ggx_vndf(O.v3(wi), alpha, C.byref(sd), out)
+        ms[i] = out[0], out[1], out[2]
+    assert np.allclose(np.linalg.norm(ms, axis=1), 1.0, atol=1e-5) and np.all(ms[:, 2] >= 0)
+    assert np.all(ms @ wi > -1e-6)  # only normals that face the viewer
+    nz, nphi, sub = 6, 8, 128
+    zi = np.minimum((ms[:, 2] * nz).astype(int), nz - 1)
+    ph = np.mod(np.arctan2(ms[:, 1], ms[:, 0]), 2 * np.pi)
+    pi_ = np.minimum((ph / (2 * np.pi) * nphi).astype(int), nphi - 1)
+    counts = np.zeros((nz, nphi))
+    np.add.at(counts, (zi, pi_), 1.0)
+    z = (np.arange(nz * sub) + 0.5) / (nz * sub)
+    phi = (np.arange(nphi * sub) + 0.5) / (nphi * sub) * 2 * np.pi
+    Z, P = np.meshgrid(z, phi, indexing="ij")
+    S = np.sqrt(1.0 - Z * Z)
+    m = np.stack([S * np.cos(P), S * np.sin(P), Z], axis=-1)
+    D = alpha * alpha / (np.pi * ((alpha * alpha - 1.0) * Z * Z + 1.0) ** 2)
+    dv = np.maximum(m @ wi, 0.0) * D / (wi[2] * (1.0 + _ggx_lambda(wi, alpha)))
+    cell = (1.0 / (nz * sub)) * (2 * np.pi / (nphi * sub))
+    model = (dv * cell).reshape(nz, sub, nphi, sub).sum(axis=(1, 3))
+    assert abs(model.sum() - 1.0) < 0.02  # the quadrature resolves the lobe
+    sigma = np.sqrt(model * (1.0 - model) / n)
+    err = np.abs(counts / n - model)
+    assert np.all(err <= 4.5 * sigma + 0.004), float((err - 4.5 * sigma).max())
+
+
+def test_free_paths_in_the_microsurface_are_exponential_in_height():
+    """Smith's model with an exponential height distribution: going up along w the chance to travel a height
+    x without meeting the surface is exp(-Lambda(w) x); going down the rate is 1 + Lambda(-w)."""
+    alpha = 0.6
+    n = 40000
+    for w in ((0.6, 0.0, 0.8), (0.95, 0.1, 0.29580399), (0.0, 0.0, 1.0), (0.6, 0.0, -0.8), (0.1, 0.9, -0.42426407)):
+        w = np.array(w) / np.linalg.norm(w)
+        up = w[2] > 0
+        lam = float(_ggx_lambda(np.array([w[0], w[1], abs(w[2])]), alpha))
+        rate = lam if up else 1.0 + lam
+        d = np.empty(n)
+        for i in range(n):
+            sd = O.Seed((i * 2654435761 + 5) & 0xFFFFFFFF, (i * 97 + 31) & 0xFFFFFFFF)
+            d[i] = O.lib.lpto_sample_ggx_height(O.v3(w), -2.0, alpha, C.byref(sd)) + 2.0
+        assert np.all(d >= 0) if up else np.all(d <= 0)
+        x = np.abs(d)
+        if rate < 1e-6:  # straight up: Lambda = 0 (the shader floors the projected area at 1e-7, heitz/BSDF.glsl:74): the ray leaves at once
+            assert np.median(x) > 1e6
+            continue
+        assert abs(x.mean() * rate - 1.0) < 4.5 / np.sqrt(n)
+        for q in (0.5, 2.0):
+            want = np.exp(-q)
+            assert abs((x * rate > q).mean() - want) < 4.5 * np.sqrt(want * (1 - want) / n)
+
+
 def test_smooth_diffuse_is_lambertian():
     for view in ((0.0, 0.0, 1.0), (0.8, 0.0, 0.6)):
         dirs, wts = _sample_bsdf(O.K_DIFF, view, 0.01, 1.5, 20000, base=(0.7, 0.7, 0.7))
