@@ -11,8 +11,11 @@
  * vectors, and its shader cannot be compiled or run in this environment
  * (no Vulkan loader, no GLSL compiler, scene-graph submodules empty).  The
  * integer RNG, the closed-form primitives and the struct layouts are pinned by
- * hand-derived vectors (tests/golden/); whole-image radiance is
- * "parity unpinned" with respect to the reference binary itself.
+ * hand-derived vectors (tests/golden/), the microfacet walk by physics and
+ * literature checks that do not depend on the shader's text (white furnace,
+ * Fresnel/Snell, Smith-GGX single scattering, visible-normal distribution:
+ * tests/test_oracle_physics.py); whole-image radiance is "parity unpinned"
+ * with respect to the reference binary itself.
  *
  * Arithmetic contract (shared, by specification, with the HIP kernels):
  *   - IEEE-754 binary32, round-to-nearest-even, no fused multiply-add,
