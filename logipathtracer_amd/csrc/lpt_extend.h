@@ -115,8 +115,11 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
   uint32_t regionsTried = 0;
 
   int state = kStFetch;
-  f3 wo{0, 0, 0}, wd{0, 0, 0}, winv{0, 0, 0};  // ray in world space
-  f3 co{0, 0, 0}, cd{0, 0, 0}, cinv{0, 0, 0};  // ray in the space being traversed
+  // The ray in world space and in the space of the object being traversed, side by side: each set has one
+  // writer (the fetch, the object entry) and `inObj` says which one a step reads, so entering and leaving an
+  // object moves no ray data around.
+  f3 wo{0, 0, 0}, wd{0, 0, 0}, winv{0, 0, 0};
+  f3 oo{0, 0, 0}, od{0, 0, 0}, oinv{0, 0, 0};
   Hit hit{kInfinity, 0u, 0u};
   bool inObj = false;
   uint32_t curObj = 0, triI = 0, triEnd = 0;
@@ -177,9 +180,6 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
             wo = f3{o.x, o.y, o.z};
             wd = f3{d.x, d.y, d.z};
             winv = f3{1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z};
-            co = wo;
-            cd = wd;
-            cinv = winv;
             hit = Hit{kInfinity, 0u, 0u};
             inObj = false;
             stk[0] = kRefSentinel;
@@ -193,6 +193,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     } else if (nI >= nT && nI >= nO) {
       LPT_XSTAT(1, nI);
       if (state == kStInner) {
+        const f3 co = inObj ? oo : wo, cinv = inObj ? oinv : winv;
         for (;;) {
           float4 q0, q1, q2, q3;
           if (CACHE > 0 && cur < (uint32_t)CACHE) {
@@ -236,7 +237,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
           for (int it = 1;; ++it) {
             const float4* tq = record_words(sc.tris, triI);
             const float4 a = tq[0], b = tq[1], c = tq[2];
-            const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
+            const float td = tri_test(oo, od, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
             if (td > kEps && td < hit.t) {
               hit.t = td;
               hit.obj = curObj;
@@ -266,27 +267,24 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
           const float4* oq = record_words(sc.otrav, first);
           const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-          co = xform_point(rows, wo);
-          cd = xform_dir(rows, wd);
+          oo = xform_point(rows, wo);
+          od = xform_dir(rows, wd);
           curObj = first;
           inObj = true;
           cur = as_uint(r3.x);
           // the reciprocal direction only feeds box tests: not needed when the mesh tree is one leaf
-          if (!(cur & kRefLeafBit)) cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
+          if (!(cur & kRefLeafBit)) oinv = f3{1.0f / od.x, 1.0f / od.y, 1.0f / od.z};
         }
         stepped = true;
       }
     }
 
     // Common tail: take the next reference off the stack if needed and decide what the
-    // lane waits for next.  Leaving an object's mesh tree restores the world-space ray.
+    // lane waits for next.
     if (stepped) {
       if (needPop) cur = stk[(--sp) * BLOCK];
       if (cur == kRefMarker) {  // only a pop yields the marker
         inObj = false;
-        co = wo;
-        cd = wd;
-        cinv = winv;
         cur = stk[(--sp) * BLOCK];
       }
       if (cur == kRefSentinel) {

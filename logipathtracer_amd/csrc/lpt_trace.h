@@ -100,7 +100,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
   // A lane is either searching for a hit or sampling the BSDF at one, never both, so the two
   // sets of per-lane variables share registers (what keeps four waves per SIMD resident):
   //            search                         surface (state kTsWalk)
-  //   A, B, C  co, cd, cinv                   shading frame u, v, ff
+  //   A, B, C  ray in the object's space      shading frame u, v, ff
+  //            (read while inObj; outside an object the search reads p.o, p.d, winv)
   //   D        winv                           baseLinear
   //   E        hit (t, obj, prim)             walk energy
   //   g0..g5   cur, sp, curObj, triI,         walk height, roughness, ior,
@@ -288,9 +289,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
       if (startSearch) {  // search view: a fresh closest-hit search along p.o / p.d
         ++nSegments;
         D = f3{1.0f / p.d.x, 1.0f / p.d.y, 1.0f / p.d.z};
-        A = p.o;
-        B = p.d;
-        C = D;
         E = f3{kInfinity, 0.0f, 0.0f};
         g5 = 0u;
         stk[0] = kRefSentinel;
@@ -304,7 +302,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     }
 
     // ---- search rounds: the kind most lanes wait for ------------------------------------
-    f3 co = A, cd = B, cinv = C;
+    // the object-space ray has one writer (the object entry) and `inObj` says which ray a step reads, so
+    // entering and leaving an object moves no ray data around
+    f3 oo = A, od = B, oinv = C;
     const f3 winv = D;
     Hit hit{E.x, as_uint(E.y), as_uint(E.z)};
     uint32_t cur = g0, curObj = g2, triI = g3, triEnd = g4;
@@ -316,6 +316,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
     if (nI >= nT && nI >= nO) {
       LPT_STAT(0, nI);
       if (state == kTsInner) {  // burst over consecutive inner nodes, as in k_extend
+        const f3 co = inObj ? oo : p.o, cinv = inObj ? oinv : winv;
         for (;;) {
           const float4* q = record_words(sc.nodes, cur);
           const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
@@ -345,7 +346,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
               nb = tq[4];
               nc = tq[5];
             }
-            const float td = tri_test(co, cd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
+            const float td = tri_test(oo, od, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z});
             if (td > kEps && td < hit.t) {
               hit.t = td;
               hit.obj = curObj;
@@ -380,28 +381,24 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
           const float4* oq = record_words(sc.otrav, first);
           const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-          co = xform_point(rows, p.o);
-          cd = xform_dir(rows, p.d);
+          oo = xform_point(rows, p.o);
+          od = xform_dir(rows, p.d);
           curObj = first;
           inObj = true;
           cur = as_uint(r3.x);
           // the reciprocal direction only feeds box tests: not needed when the mesh tree is one leaf
-          if (!(cur & kRefLeafBit)) cinv = f3{1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z};
+          if (!(cur & kRefLeafBit)) oinv = f3{1.0f / od.x, 1.0f / od.y, 1.0f / od.z};
         }
         stepped = true;
       }
     }
 
     // Common tail of the search steps: take the next reference off the stack if needed and
-    // decide what the lane waits for next.  Leaving an object's mesh tree restores the
-    // world-space ray.
+    // decide what the lane waits for next.
     if (stepped) {
       if (needPop) cur = stk[(--sp) * BLOCK];
       if (cur == kRefMarker) {  // only a pop yields the marker
         inObj = false;
-        co = p.o;
-        cd = p.d;
-        cinv = winv;
         cur = stk[(--sp) * BLOCK];
       }
       if (cur == kRefSentinel) {
@@ -415,9 +412,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
       } else {
         state = kTsObj;
       }
-      A = co;
-      B = cd;
-      C = cinv;
+      A = oo;
+      B = od;
+      C = oinv;
       E = f3{hit.t, as_float(hit.obj), as_float(hit.prim)};
       g0 = cur;
       g1 = (uint32_t)sp;
