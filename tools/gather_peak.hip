@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x)                                                                      \
@@ -39,13 +40,16 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 // four pieces of the record that lane-group k draws (PIECES must be 4).  SHARE > 1: groups of SHARE
 // neighbouring lanes draw the same record and each reads all of it (lanes of the search that stand at the
 // same node: the L1 then serves one access for the group).
+// `active` < 0: the -active lanes that take part are spread over the wave (lane numbers in bit-reversed order: 32
+// lanes = every other lane, 16 lanes = one lane in every group of four) instead of being the lowest ones.
 template <int PIECES, bool QUAD, int SHARE = 1>
 __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ table, uint32_t nRecords, int iters,
                                                 int active, float* __restrict__ out) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.0f;
-  if ((int)lane < active) {
+  const uint32_t spread = __brev(lane) >> 26;  // 6-bit reversal
+  if (active >= 0 ? (int)lane < active : (int)spread < -active) {
     uint32_t s = mix(QUAD ? (gid >> 2) + 1u : (gid / (uint32_t)SHARE) + 1u);
     constexpr int U = 4;  // independent records in flight per lane
     for (int it = 0; it < iters; it += U) {
@@ -78,7 +82,8 @@ struct Case {
   int share;
 };
 
-int main() {
+int main(int argc, char** argv) {
+  const bool spreadOnly = argc > 1 && std::string(argv[1]) == "spread";
   int dev = 0;
   CHECK(hipSetDevice(dev));
   hipDeviceProp_t prop;
@@ -100,10 +105,12 @@ int main() {
                         {"quad_64B", 4, true, 1},        {"lane_64B_share2", 4, false, 2}, {"lane_64B_share4", 4, false, 4},
                         {"lane_64B_share8", 4, false, 8}};
   const size_t sizes[] = {16u << 10, 1u << 20, 2u << 20, 16u << 20, 48u << 20};
-  const int actives[] = {64, 48, 32, 16};
+  // "spread": only the plain 64-byte records, lowest lanes against lanes spread over the wave
+  const std::vector<int> actives = spreadOnly ? std::vector<int>{64, 32, -32, 16, -16, 8, -8} : std::vector<int>{64, 48, 32, 16};
   for (const Case& c : cases)
     for (size_t bytes : sizes)
       for (int active : actives) {
+        if (spreadOnly && (c.pieces != 4 || c.quad || c.share != 1 || bytes > (2u << 20))) continue;
         const uint32_t nRec = (uint32_t)(bytes / 64);
         const int iters = 2048;
         auto launch = [&]() {
@@ -125,13 +132,14 @@ int main() {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         const double waves = (double)blocks * 4.0;
         // records read: per-lane forms one record per active lane and iteration; the quad form one per four lanes
-        const double recs = waves * iters * (c.quad ? active / 4.0 : (double)active);
+        const int nActive = active < 0 ? -active : active;
+        const double recs = waves * iters * (c.quad ? nActive / 4.0 : (double)nActive);
         const double bytesRead = recs * 16.0 * c.pieces;
         const double waveInstr = waves * iters * (c.quad ? 1.0 : (double)c.pieces);
-        std::printf("{\"case\": \"%s\", \"table_bytes\": %zu, \"active_lanes\": %d, \"ms\": %.4f, \"records_per_s\": %.4g, "
+        std::printf("{\"case\": \"%s\", \"table_bytes\": %zu, \"active_lanes\": %d, \"spread\": %d, \"ms\": %.4f, \"records_per_s\": %.4g, "
                     "\"gbytes_per_s\": %.1f, \"bytes_per_clk_per_cu\": %.2f, \"clk_per_wave_instr_per_cu\": %.2f, "
                     "\"cus\": %d, \"clock_ghz\": %.3f}\n",
-                    c.name, bytes, active, ms, recs / (ms * 1e-3), bytesRead / (ms * 1e-3) / 1e9,
+                    c.name, bytes, nActive, active < 0 ? 1 : 0, ms, recs / (ms * 1e-3), bytesRead / (ms * 1e-3) / 1e9,
                     bytesRead / (ms * 1e-3) / (cus * clockGHz * 1e9), (ms * 1e-3) * clockGHz * 1e9 * cus / waveInstr, cus,
                     clockGHz);
         std::fflush(stdout);
