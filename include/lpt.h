@@ -97,8 +97,9 @@ enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
  * AUTO (default): HYBRID; WAVEFRONT for batches of 24 Mi paths and more; PERSISTENT when
  *            the ray queues do not fit in device memory.
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (128 bytes of
- *            queues per path in flight); the first segment runs in the packet kernel, bounces
- *            from the fourth on in one persistent launch.
+ *            queues per path in flight); the first segment runs in the packet kernel, and from the
+ *            bounce at which the queues have become short (by the last batch's fills) one persistent
+ *            launch finishes the paths.
  * MEGAKERNEL: one thread per pixel runs the whole path (the shader's own organisation).
  * PERSISTENT: one launch per batch, paths stay in registers from the camera ray on (16 bytes
  *            per path in flight).
