@@ -227,3 +227,78 @@ def test_upload_refuses_buffers_a_traversal_could_not_walk(device, cornell):
     finally:
         device.upload_scene(cornell)  # the session's device goes on with a sound scene
     assert refused > 300 and accepted > 50, (accepted, refused)
+
+
+def _chain_scene(n_tris):
+    """One object whose mesh tree is a chain: inner node k holds leaf k (pushed) and inner node k + 1 (visited
+    first), so a ray through all the boxes stacks one leaf per level: the traversal needs about n_tris + 2 entries."""
+    objects = np.zeros(1, dtype=L._native.OBJECT_DTYPE)
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    objects["worldMatrix"][0] = eye
+    objects["worldMatrixInverse"][0] = eye
+    objects["baseColorFactor"][0] = (0.8, 0.7, 0.6, 1.0)
+    objects["emissionFactor"][0] = (0.5, 0.25, 0.125)
+    objects["roughnessFactor"][0] = 0.5
+    objects["ior"][0] = 1.5
+    for t in ("colorTexture", "emissionTexture", "metallicRoughnessTexture", "transmissionTexture", "normalTexture"):
+        objects[t][0] = 0xFFFFFFFF
+    vertices = np.zeros(3 * n_tris, dtype=L._native.VERTEX_DTYPE)
+    for k in range(n_tris):  # triangles stacked along z, shrinking towards the camera so that each is partly visible
+        s = 1.0 - 0.5 * k / n_tris
+        vertices["position"][3 * k:3 * k + 3] = [(-s, -s, 0.05 * k), (s, -s, 0.05 * k), (0.0, s, 0.05 * k)]
+    vertices["normal"][:] = (0.0, 0.0, 1.0)
+    n_nodes = 2 * n_tris - 1
+    nodes = np.zeros(n_nodes, dtype=L._native.NODE_DTYPE)
+
+    def bounds(lo, hi):
+        p = vertices["position"][3 * lo:3 * hi]
+        return p.min(axis=0), p.max(axis=0)
+
+    for k in range(n_tris - 1):
+        inner, leaf = 2 * k, 2 * k + 1
+        nodes["minCorner"][inner], nodes["maxCorner"][inner] = bounds(k, n_tris)
+        nodes["indices"][inner] = (leaf, 2 * (k + 1))  # x = this level's leaf, y = the rest of the chain
+        nodes["minCorner"][leaf], nodes["maxCorner"][leaf] = bounds(k, k + 1)
+        nodes["isLeaf"][leaf] = 1
+        nodes["indices"][leaf] = (k, k + 1)
+    last = 2 * (n_tris - 1)
+    nodes["minCorner"][last], nodes["maxCorner"][last] = bounds(n_tris - 1, n_tris)
+    nodes["isLeaf"][last] = 1
+    nodes["indices"][last] = (n_tris - 1, n_tris)
+    obvh = np.zeros(1, dtype=L._native.NODE_DTYPE)
+    obvh["minCorner"][0], obvh["maxCorner"][0] = bounds(0, n_tris)
+    obvh["isLeaf"][0] = 1
+    obvh["indices"][0] = (0, 1)
+    cam = np.eye(4, dtype=np.float32)
+    cam[3, :3] = (0.0, 0.0, 6.0)  # row-major view of the column-major matrix: translation in elements 12..14
+    return L.Scene.from_buffers(objects, obvh, vertices, nodes, cam.reshape(16), 0.6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_tris", [14, 22, 30, 44, 60])
+def test_deep_trees_run_on_the_larger_stack_variants(device, n_tris):
+    """Chains of 14 to 60 levels need 16 to 62 stack entries: every stack size the kernels are built for
+    (16, 20, 24, 32, 48, 64) traces them like the oracle."""
+    s = _chain_scene(n_tris)
+    osc = O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
+    ubos = L.frame_ubos(s.camera_world, s.fov_y, 2, seed=n_tris)
+    w, h, bounces = 40, 40, 3
+    ref, st = O.render_frames(osc, ubos, w, h, bounces)
+    assert st["stackOverflow"] == 0 and st["maxStackBlas"] >= n_tris
+    assert st["hits"] > 0
+    device.upload_scene(s)
+    for pipeline in PIPELINES:
+        device.resize(w, h)
+        device.set_options(bounces, L.BSDF_HEITZ, pipeline, 0)
+        device.render_frames(ubos)
+        assert device.stats().segments == st["segments"], (n_tris, pipeline)
+        assert _same(device.read_accum(), ref), (n_tris, pipeline)
+
+
+@pytest.mark.gpu
+def test_a_tree_deeper_than_the_largest_stack_is_refused(device, cornell):
+    try:
+        with pytest.raises(L.LptError, match="stack"):
+            device.upload_scene(_chain_scene(80))
+    finally:
+        device.upload_scene(cornell)
