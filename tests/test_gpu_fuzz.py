@@ -302,3 +302,52 @@ def test_a_tree_deeper_than_the_largest_stack_is_refused(device, cornell):
             device.upload_scene(_chain_scene(80))
     finally:
         device.upload_scene(cornell)
+
+
+@pytest.mark.gpu
+def test_object_tree_shapes_the_converter_never_emits(device, cornell):
+    """Object trees are the caller's: one leaf naming all objects, leaves of several objects beside an empty leaf,
+    and instances (objects that share a mesh tree and its vertices under different transforms) trace like the oracle."""
+    n = len(cornell.objects)
+    boxes_lo = cornell.object_bvh["minCorner"].min(axis=0)
+    boxes_hi = cornell.object_bvh["maxCorner"].max(axis=0)
+
+    def node(leaf, a, b, lo=boxes_lo, hi=boxes_hi):
+        r = np.zeros(1, dtype=L._native.NODE_DTYPE)
+        r["minCorner"][0], r["maxCorner"][0], r["isLeaf"][0], r["indices"][0] = lo, hi, leaf, (a, b)
+        return r
+
+    # an instance: the last object again, moved up by 0.3 (its inverse matrix moves rays down by 0.3)
+    objects = np.concatenate([cornell.objects, cornell.objects[-1:]])
+    wm = objects["worldMatrix"][-1].reshape(4, 4).copy()   # column-major: row 3 of this view is the translation
+    wi = objects["worldMatrixInverse"][-1].reshape(4, 4).copy()
+    shift = np.eye(4, dtype=np.float32)
+    shift[3, 1] = 0.3
+    unshift = np.eye(4, dtype=np.float32)
+    unshift[3, 1] = -0.3
+    objects["worldMatrix"][-1] = (wm @ shift).reshape(16)        # world = T * M  (column-major product, row view)
+    objects["worldMatrixInverse"][-1] = (unshift @ wi).reshape(16)  # inverse = M^-1 * T^-1
+    big_lo, big_hi = boxes_lo - 0.5, boxes_hi + 0.5
+    shapes = {
+        "one leaf": (cornell.objects, node(1, 0, n)),
+        "leaves of several objects and an empty one": (cornell.objects, np.concatenate([
+            node(0, 1, 2), node(0, 3, 4), node(1, 5, 5), node(1, 0, 6), node(1, 6, n)])),
+        "instance": (objects, np.concatenate([node(0, 1, 2, big_lo, big_hi), node(1, 0, n, big_lo, big_hi),
+                                              node(1, n, n + 1, big_lo, big_hi)])),
+    }
+    try:
+        for name, (objs, obvh) in shapes.items():
+            s = L.Scene.from_buffers(objs, obvh, cornell.vertices, cornell.mesh_bvh, cornell.camera_world, cornell.fov_y)
+            osc = O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
+            ubos = L.frame_ubos(s.camera_world, s.fov_y, 2, seed=17)
+            w, h, bounces = 96, 64, 6
+            ref, st = O.render_frames(osc, ubos, w, h, bounces)
+            device.upload_scene(s)
+            for pipeline in PIPELINES:
+                device.resize(w, h)
+                device.set_options(bounces, L.BSDF_HEITZ, pipeline, 0)
+                device.render_frames(ubos)
+                assert device.stats().segments == st["segments"], (name, pipeline)
+                assert _same(device.read_accum(), ref), (name, pipeline)
+    finally:
+        device.upload_scene(cornell)
