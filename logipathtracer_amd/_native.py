@@ -108,6 +108,7 @@ _sig(hip, "lpt_debug_math", _i, _vp, _i, _vp, _vp, _vp, _u32)
 _sig(hip, "lpt_debug_intersect", _i, _vp, _vp, _vp, _u32, _vp, _vp, _vp)
 
 _sig(host, "lpth_last_error", C.c_char_p)
+_sig(host, "lpth_write_png", _i, C.c_char_p, _vp, _u32, _u32, _i)
 _sig(host, "lpth_scene_load", _vp, C.c_char_p, _i, _vp)
 _sig(host, "lpth_scene_free", None, _vp)
 _sig(host, "lpth_scene_counts", None, _vp, C.POINTER(_u32 * 5))

@@ -43,6 +43,15 @@ def frame_ubos(camera_world, fov_y, n_frames, seed=0x5EED, first_reset=True):
     return u
 
 
+def write_png(path, pixels):
+    """Writes an (H, W, 3) or (H, W, 4) uint8 array as a PNG file through the host library's encoder."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if px.ndim != 3 or px.shape[2] not in (3, 4):
+        raise ValueError("pixels must be (H, W, 3) or (H, W, 4)")
+    if N.host.lpth_write_png(str(path).encode(), _ptr(px), px.shape[1], px.shape[0], px.shape[2]) != 0:
+        raise LptError(-1, N.host.lpth_last_error().decode())
+
+
 class Scene:
     """glTF file -> flattened scene buffers via the native PTSceneConverter."""
 

@@ -1,13 +1,16 @@
 // Flat C entry points over the C++ host classes, for bindings (ctypes) and tests.
 // Every function catches C++ exceptions and reports them through an error string.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <stdexcept>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "glibc_rand.hpp"
+#include "png_decode.hpp"
 #include "pt_scene_converter.hpp"
 #include "renderer_pt.hpp"
 
@@ -50,6 +53,21 @@ int guarded(F&& f) {
 extern "C" {
 
 const char* lpth_last_error() { return g_error.c_str(); }
+
+// ---- images ---------------------------------------------------------------------------------
+
+// Writes 8-bit RGB (channels 3) or RGBA (4) pixels, row 0 first, to `path` as a PNG file.
+int lpth_write_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, int channels) {
+  return guarded([&] {
+    std::vector<uint8_t> file;
+    lsg::encodePNG(pixels, width, height, channels, file);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+    const size_t n = std::fwrite(file.data(), 1, file.size(), f);
+    std::fclose(f);
+    if (n != file.size()) throw std::runtime_error(std::string("short write to ") + path);
+  });
+}
 
 // ---- scene conversion (PTSceneConverter) ------------------------------------------------
 

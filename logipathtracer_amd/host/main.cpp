@@ -1,6 +1,6 @@
 // Headless command-line driver standing in for the interactive loop of the reference
 // (src/Main.cpp): loads a glTF file, renders a number of samples per pixel with RendererPT
-// and writes the accumulated radiance (PFM) and the display image (PPM).
+// and writes the accumulated radiance (PFM) and the display image (PPM and PNG).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "png_decode.hpp"
 #include "renderer_pt.hpp"
 
 static void writePFM(const std::string& path, const std::vector<float>& rgba, int w, int h, float scale) {
@@ -37,6 +38,21 @@ static void writePPM(const std::string& path, const std::vector<float>& rgba, in
       }
     std::fwrite(row.data(), 1, row.size(), f);
   }
+  std::fclose(f);
+}
+
+static void writePNG(const std::string& path, const std::vector<float>& rgba, int w, int h) {
+  std::vector<uint8_t> px(3 * (size_t)w * h), file;
+  for (size_t i = 0; i < (size_t)w * h; ++i)
+    for (int c = 0; c < 3; ++c) {
+      float v = rgba[4 * i + c];
+      v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+      px[3 * i + c] = (unsigned char)(v * 255.0f + 0.5f);
+    }
+  lsg::encodePNG(px.data(), (uint32_t)w, (uint32_t)h, 3, file);
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) throw std::runtime_error("cannot write " + path);
+  std::fwrite(file.data(), 1, file.size(), f);
   std::fclose(f);
 }
 
@@ -87,7 +103,8 @@ int main(int argc, char** argv) {
     renderer.resolve(display);
     writePFM(out + ".pfm", accum, width, height, 1.0f / (float)spp);
     writePPM(out + ".ppm", display, width, height);
-    std::cout << "wrote " << out << ".pfm and " << out << ".ppm (" << renderer.samples() << " spp)\n";
+    writePNG(out + ".png", display, width, height);
+    std::cout << "wrote " << out << ".pfm, " << out << ".ppm and " << out << ".png (" << renderer.samples() << " spp)\n";
   } catch (const std::exception& e) {
     std::cerr << "error: " << e.what() << "\n";
     return 1;

@@ -173,4 +173,41 @@ void decodePNG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, uin
   height = h;
 }
 
+void encodePNG(const uint8_t* pixels, uint32_t width, uint32_t height, int channels, std::vector<uint8_t>& out) {
+  if (!pixels || width == 0 || height == 0 || (channels != 3 && channels != 4))
+    throw std::runtime_error("PNG: nothing to encode");
+  const size_t rowBytes = (size_t)width * (size_t)channels;
+  std::vector<uint8_t> raw((rowBytes + 1) * (size_t)height);
+  for (uint32_t y = 0; y < height; ++y) {  // filter type 0 (none) in front of every scan line
+    raw[(rowBytes + 1) * y] = 0;
+    std::memcpy(&raw[(rowBytes + 1) * y + 1], pixels + rowBytes * y, rowBytes);
+  }
+  uLongf packedSize = compressBound((uLong)raw.size());
+  std::vector<uint8_t> packed(packedSize);
+  if (compress2(packed.data(), &packedSize, raw.data(), (uLong)raw.size(), 6) != Z_OK)
+    throw std::runtime_error("PNG: compression failed");
+  packed.resize(packedSize);
+  auto be32 = [](std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+  };
+  auto chunk = [&](const char* tag, const std::vector<uint8_t>& data) {
+    be32(out, (uint32_t)data.size());
+    const size_t start = out.size();
+    out.insert(out.end(), tag, tag + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    be32(out, (uint32_t)crc32(0L, out.data() + start, (uInt)(out.size() - start)));
+  };
+  static const uint8_t signature[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+  out.assign(signature, signature + 8);
+  std::vector<uint8_t> ihdr;
+  be32(ihdr, width);
+  be32(ihdr, height);
+  ihdr.push_back(8);                                    // bit depth
+  ihdr.push_back(channels == 4 ? 6 : 2);                // colour type: RGBA / RGB
+  ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);  // deflate, adaptive filtering, not interlaced
+  chunk("IHDR", ihdr);
+  chunk("IDAT", packed);
+  chunk("IEND", {});
+}
+
 }  // namespace lsg

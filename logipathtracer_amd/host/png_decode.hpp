@@ -11,4 +11,7 @@ namespace lsg {
 // Throws std::runtime_error with a message naming what is wrong or unsupported.
 void decodePNG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, uint32_t& width, uint32_t& height);
 
+// 8-bit RGB (channels = 3) or RGBA (4) pixels, row 0 first, as a PNG file image (one IDAT chunk, no interlace).
+void encodePNG(const uint8_t* pixels, uint32_t width, uint32_t height, int channels, std::vector<uint8_t>& out);
+
 }  // namespace lsg

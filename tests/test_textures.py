@@ -132,6 +132,35 @@ def _one_texture_scene(tmp_path, image_name):
     return L.Scene(path)
 
 
+@pytest.mark.parametrize("shape", [(13, 21, 3), (1, 1, 4), (64, 48, 4), (7, 300, 3)])
+def test_png_writer_round_trips_through_the_png_reader(tmp_path, shape):
+    """The host library's PNG encoder (what lpt_render writes its display image with) against its own reader
+    and, where importable, PIL."""
+    from logipathtracer_amd import scenes as _scenes
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    px = rng.integers(0, 256, shape).astype(np.uint8)
+    L.write_png(tmp_path / "w.png", px)
+    g = _scenes._GltfBuilder()
+    quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+    m = g.material("M", (1, 1, 1, 1), 0.0, 0.5, base_tex=g.texture("w.png"))
+    g.node("Q", mesh=g.mesh("Q", [(quad, np.tile([0, 1, 0], (4, 1)).astype(np.float32), np.array([0, 2, 1, 0, 3, 2], np.uint32), m,
+                                   np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32))]))
+    g.node("Camera", camera=g.camera(0.8), translation=(0, 3, 0))
+    g.write(str(tmp_path / "readback.gltf"))
+    back = L.Scene(str(tmp_path / "readback.gltf")).textures[0]["pixels"]
+    assert back.shape == shape[:2] + (4,)
+    assert np.array_equal(back[..., :shape[2]], px)
+    if shape[2] == 3:
+        assert np.all(back[..., 3] == 255)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "w.png")), px)
+    with pytest.raises(ValueError):
+        L.write_png(tmp_path / "bad.png", px[..., :1])
+
+
 def test_missing_and_damaged_images_are_rejected_with_a_message(tmp_path):
     with pytest.raises(L.LptError, match="failed to open"):
         _one_texture_scene(tmp_path, "photo.jpg")
@@ -324,3 +353,15 @@ def test_command_line_renderer_writes_the_same_image(textured, tmp_path, device)
         ppm = np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
     disp = np.clip(O.resolve(acc, 1.0 / spp)[..., :3], 0.0, 1.0)
     assert np.abs(ppm.astype(np.int32) - (disp * 255.0 + 0.5).astype(np.int32)).max() <= 1
+    # the PNG holds the same bytes as the PPM (read back with the package's own PNG reader, via a one-quad scene)
+    from logipathtracer_amd import scenes as _scenes
+    g = _scenes._GltfBuilder()
+    quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+    t = g.texture(os.path.basename(out) + ".png")
+    m = g.material("M", (1, 1, 1, 1), 0.0, 0.5, base_tex=t)
+    g.node("Q", mesh=g.mesh("Q", [(quad, np.tile([0, 1, 0], (4, 1)).astype(np.float32), np.array([0, 2, 1, 0, 3, 2], np.uint32), m,
+                                   np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32))]))
+    g.node("Camera", camera=g.camera(0.8), translation=(0, 3, 0))
+    g.write(str(tmp_path / "readback.gltf"))
+    back = L.Scene(str(tmp_path / "readback.gltf")).textures[0]["pixels"]
+    assert back.shape == (h, w, 4) and np.array_equal(back[..., :3], ppm) and np.all(back[..., 3] == 255)
