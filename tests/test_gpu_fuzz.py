@@ -351,3 +351,45 @@ def test_object_tree_shapes_the_converter_never_emits(device, cornell):
                 assert _same(device.read_accum(), ref), (name, pipeline)
     finally:
         device.upload_scene(cornell)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1], ids=["lbvh", "ploc"])
+def test_gpu_builders_keep_their_shape_on_hostile_triangles(device, which):
+    """NaN and infinite corners, coordinates 30 orders of magnitude apart, all triangles on one line or in one point:
+    the GPU builders still return a tree over every triangle exactly once with leaves of at most four (boxes of
+    non-finite input are whatever min/max make of it), or refuse with a message; they never hang or fault."""
+    rng = np.random.default_rng(5 + which)
+    n = 777
+    base = (rng.uniform(-1, 1, size=(n, 1, 3)) + rng.uniform(-0.05, 0.05, size=(n, 3, 3))).astype(np.float32)
+    cases = {}
+    c = base.copy(); c[rng.random(n) < 0.1] = np.nan; cases["a tenth NaN"] = c
+    c = base.copy(); c[:] = np.nan; cases["all NaN"] = c
+    c = base.copy(); c[rng.random(n) < 0.05, 0, 0] = np.inf; c[rng.random(n) < 0.05, 1, 2] = -np.inf; cases["infinities"] = c
+    c = base.copy(); c[::7] *= 1e30; c[1::7] *= 1e-30; cases["sixty orders of magnitude"] = c
+    c = np.zeros_like(base); c[:, :, 0] = np.linspace(0, 1, n)[:, None]; cases["on one line"] = c
+    cases["one point"] = np.full_like(base, 0.25)
+    c = base.copy(); c[:] = 3.0e38; cases["at the top of the float range"] = c
+    for name, corners in cases.items():
+        try:
+            nodes, order = device.build_mesh_bvh(corners, which)
+        except L.LptError as e:
+            assert str(e), name
+            continue
+        assert sorted(order.tolist()) == list(range(n)), name
+        assert 1 <= len(nodes) <= 2 * n - 1, name
+        seen = np.zeros(n, dtype=np.int32)
+        visited = set()
+        stack = [0]
+        while stack:
+            i = stack.pop()
+            assert i not in visited and i < len(nodes), name
+            visited.add(i)
+            nd = nodes[i]
+            a, b = int(nd["indices"][0]), int(nd["indices"][1])
+            if nd["isLeaf"]:
+                assert 0 < b - a <= 4 and b <= n, name
+                seen[a:b] += 1
+            else:
+                stack += [a, b]
+        assert np.all(seen == 1), name
