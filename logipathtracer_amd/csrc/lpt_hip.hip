@@ -109,6 +109,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
 // Closest hit for every queued ray: persistent waves, node stacks in LDS, rays handed out
 // through `cursor` (one set of cursors, kCursorWords words zeroed before the launch).  See lpt_extend.h.
 template <int S>
+#ifdef LPT_EXTEND_WAVES_PER_SIMD  // comparison builds: resident waves per SIMD forced (default: what registers and LDS allow, 7)
+__attribute__((amdgpu_waves_per_eu(LPT_EXTEND_WAVES_PER_SIMD, LPT_EXTEND_WAVES_PER_SIMD)))
+#endif
 __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
                                                    const float4* __restrict__ qd, QueueFill fill,
                                                    float4* __restrict__ hits, uint32_t* cursor) {
