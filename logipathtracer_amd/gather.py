@@ -23,16 +23,16 @@ def owned_accum_tensor(dev, torch_device):
 
 
 def gather_image(dev, world, width, height, torch_device, backend="nccl"):
-    """All ranks call this after rendering.  Returns (image, milliseconds of the collective): `image` is a
-    (height, width, 4) float32 device tensor holding every rank's pixels (on every rank).
+    """All ranks call this after rendering.  Returns (image, milliseconds of the collective, bytes every rank
+    received): `image` is a (height, width, 4) float32 device tensor holding every rank's pixels (on every rank).
     `backend` "nccl" gathers device to device; "gloo" (rehearsals on fewer GPUs than ranks) goes through
     host memory."""
     import torch
     import torch.distributed as dist
     dev.synchronize()
-    # The collective reads a torch-owned copy of the compact buffer (16 bytes per owned pixel: a few tens of MB):
-    # RCCL then only ever sees memory of the allocator it is tested with, never the library's own hipMalloc block.
-    mine = owned_accum_tensor(dev, torch_device).clone()
+    # The collective reads the context's compact buffer in place: the tensor below aliases the device memory
+    # lpt_owned_accum_device points at (plain hipMalloc memory, which RCCL takes like any other device pointer).
+    mine = owned_accum_tensor(dev, torch_device)
     n_floats = mine.numel()
     gathered = torch.empty(world * n_floats, dtype=torch.float32, device=torch_device)
     torch.cuda.synchronize(torch_device)
@@ -49,4 +49,4 @@ def gather_image(dev, world, width, height, torch_device, backend="nccl"):
     image = torch.empty(height * width * 4, dtype=torch.float32, device=torch_device)
     dev.assemble_gathered(gathered.data_ptr(), world, image.data_ptr())
     dev.synchronize()
-    return image.view(height, width, 4), ms
+    return image.view(height, width, 4), ms, world * n_floats * 4

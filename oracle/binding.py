@@ -115,9 +115,35 @@ class OracleScene:
                        C.cast(self.tex_array, C.c_void_p).value if textures else None, len(textures))
 
 
-def render_frames(scene, ubos, width, height, max_bounces, bsdf_mode=BSDF_HEITZ, tile=None, threads=0, accum=None):
+_libm_variant = None
+
+
+def libm_variant():
+    """The same restatement built with the C library's sinf/cosf/tanf/logf/expf/powf in place of the fixed
+    polynomials (oracle/Makefile, -DLPTO_LIBM); pass it as `library=` to render_frames."""
+    global _libm_variant
+    if _libm_variant is None:
+        path = os.path.join(_HERE, "build", "liblpt_oracle_libm.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: run `make -C oracle`")
+        v = C.CDLL(path)
+        v.lpto_render_frame.restype = C.c_int
+        v.lpto_render_frame.argtypes = [C.POINTER(Scene), C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
+        for n in ("lpto_sin", "lpto_cos", "lpto_tan", "lpto_log", "lpto_exp"):
+            getattr(v, n).restype = C.c_float
+            getattr(v, n).argtypes = [C.c_float]
+        v.lpto_pow.restype = C.c_float
+        v.lpto_pow.argtypes = [C.c_float, C.c_float]
+        _libm_variant = v
+    return _libm_variant
+
+
+def render_frames(scene, ubos, width, height, max_bounces, bsdf_mode=BSDF_HEITZ, tile=None, threads=0, accum=None,
+                  library=None):
     """Renders the frames described by `ubos` (records with the 92-byte uniform layout) in order
-    into an RGBA32F accumulation image; returns (image, summed stats dict)."""
+    into an RGBA32F accumulation image; returns (image, summed stats dict).  `library`: another build of the
+    oracle (libm_variant()) instead of the default one."""
+    use = library if library is not None else lib
     if accum is None:
         accum = np.zeros((height, width, 4), dtype=np.float32)
     x0, y0, w, h = tile if tile else (0, 0, width, height)
@@ -127,7 +153,7 @@ def render_frames(scene, ubos, width, height, max_bounces, bsdf_mode=BSDF_HEITZ,
     assert ubos.dtype.itemsize == 92
     for i in range(len(ubos)):
         st = Stats()
-        rc = lib.lpto_render_frame(C.byref(scene.c), ubos[i:i + 1].ctypes.data, C.byref(p), accum.ctypes.data, C.byref(st))
+        rc = use.lpto_render_frame(C.byref(scene.c), ubos[i:i + 1].ctypes.data, C.byref(p), accum.ctypes.data, C.byref(st))
         if rc != 0:
             raise RuntimeError(f"lpto_render_frame failed with {rc}")
         for k, v in st.as_dict().items():

@@ -73,9 +73,20 @@ static inline v3 mat3_vec(const float* m, v3 v) {
 }
 
 /* --- fixed transcendental algorithms (single precision, Cephes-style minimax
- *     polynomials; only + - * / floor and bit operations) ------------------- */
+ *     polynomials; only + - * / floor and bit operations) -------------------
+ * GLSL leaves the precision of sin, cos, tan, log, exp and pow to the implementation
+ * (the calls: heitz/BSDF.glsl:55-56,81, common/util.glsl:7, path_tracing.comp:119).
+ * The contract with the HIP kernels fixes them as the polynomials below.  A second
+ * build, -DLPTO_LIBM (build/liblpt_oracle_libm.so), calls the C library instead: a
+ * different, equally legitimate implementation of the same shader, used by the
+ * tests to show that the converged image does not depend on which one is taken. */
 
 static void sincos_(float x, float* s, float* c) {
+#ifdef LPTO_LIBM
+  *s = sinf(x);
+  *c = cosf(x);
+  return;
+#endif
   if (!(fabsf(x) <= 8192.0f)) { /* NaN, inf, out of the reduction's range */
     *s = *c = u2f(0x7fc00000u);
     return;
@@ -100,9 +111,16 @@ static void sincos_(float x, float* s, float* c) {
 
 float lpto_sin(float x) { float s, c; sincos_(x, &s, &c); return s; }
 float lpto_cos(float x) { float s, c; sincos_(x, &s, &c); return c; }
+#ifdef LPTO_LIBM
+float lpto_tan(float x) { return tanf(x); }
+#else
 float lpto_tan(float x) { float s, c; sincos_(x, &s, &c); return s / c; }
+#endif
 
 float lpto_log(float x) {
+#ifdef LPTO_LIBM
+  return logf(x);
+#endif
   if (x != x) return x;
   if (x < 0.0f) return u2f(0x7fc00000u);
   if (x == 0.0f) return u2f(0xff800000u);
@@ -135,6 +153,9 @@ float lpto_log(float x) {
 }
 
 float lpto_exp(float x) {
+#ifdef LPTO_LIBM
+  return expf(x);
+#endif
   if (x != x) return x;
   if (x > 88.72283905206835f) return u2f(0x7f800000u);
   if (x < -103.278929903431851103f) return 0.0f;
@@ -154,6 +175,9 @@ float lpto_exp(float x) {
 }
 
 float lpto_pow(float x, float y) {
+#ifdef LPTO_LIBM
+  return powf(x, y);
+#endif
   if (x != x || y != y) return u2f(0x7fc00000u);
   if (x < 0.0f) return u2f(0x7fc00000u);
   if (x == 0.0f) {

@@ -34,7 +34,8 @@ dev.set_partition(32, 32, 0, 1)      # tiles that stick out of the image: the co
 dev.set_options(4, L.BSDF_HEITZ, L.PIPELINE_AUTO, 0)
 dev.render_frames(ubos)
 want = dev.read_accum()
-image, ms = gather_image(dev, 1, w, h, torch.device("cuda", 0), "nccl")
+image, ms, nbytes = gather_image(dev, 1, w, h, torch.device("cuda", 0), "nccl")
+assert nbytes == dev.owned_slots() * 16
 got = image.cpu().numpy()
 assert got.shape == want.shape and np.array_equal(got, want), "gathered image differs"
 assert np.all(got[..., 3] == 2.0)
@@ -89,6 +90,32 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["camera_paths"] == 320 * 184 * 4 * 1  # 2 spp per GPU x 2 ranks, one timed step
     assert out["gather_ms"] is not None and out["config"]["tile"] == 64
+    # evidence that two ranks took part, where, and how evenly
+    assert out["ranks_seen"] == 2 and [r["rank"] for r in out["ranks"]] == [0, 1]
+    for r in out["ranks"]:
+        assert r["device"]["device_index"] == 0 and r["device_ms"] > 0 and r["segments"] > 0 and r["owned_slots"] > 0
+    assert out["ranks"][0]["pid"] != out["ranks"][1]["pid"]
+    assert out["distinct_gpus"] == 1 and out["backend"] == "gloo"  # the rehearsal shares the one GPU of the box
+    assert out["imbalance"] >= 1.0
+    assert out["gather_bytes"] == 2 * out["ranks"][0]["owned_slots"] * 16
+    assert sum(r["segments"] for r in out["ranks"]) == out["traced_segments"]
+    assert out["image_check"]["alpha_equals_samples"] and out["image_check"]["finite"]
+    assert out["image_check"]["samples_per_pixel"] == 8.0  # 4 spp per step, one warm-up and one timed step
+
+
+def test_bench_strong_scaling_keeps_the_total_samples():
+    """--scaling strong: spp per step does not grow with the ranks, so each rank's batch shrinks."""
+    env = _env()
+    env["LPT_BENCH_BACKEND"] = "gloo"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--spp-per-step", "2", "--width", "320", "--height", "184", "--no-cpu-baseline", "--scaling", "strong"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["spp_per_step"] == 2
+    assert out["camera_paths"] == 320 * 184 * 2
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():

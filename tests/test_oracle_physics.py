@@ -318,3 +318,56 @@ def test_deeper_paths_only_add_light_in_the_closed_part_of_the_box(cornell, corn
     gains = np.diff(means)
     assert np.all(gains > -0.01 * means[-1])
     assert gains[0] > gains[2] - 0.01 * means[-1]
+
+
+def test_libm_variant_converges_to_the_same_image(cornell, cornell_oracle):
+    """GLSL leaves the precision of sin, cos, tan, log, exp and pow open (the calls: heitz/BSDF.glsl:55-56,81,
+    common/util.glsl:7, path_tracing.comp:119); the arithmetic contract fixes them as polynomials.  A second build
+    of the restatement calls the C library instead (oracle/Makefile, -DLPTO_LIBM) — another legitimate
+    implementation of the same shader.  Rendered with the same seeds, the two differ only where a rounding
+    difference flips a branch; such flips must not bias the estimator: the converged images agree within Monte-Carlo
+    noise, pixel by pixel, and far more closely than two independent renders do."""
+    w = h = 128
+    bounces, chunks, per_chunk = 8, 16, 256  # 4096 samples per pixel
+    libm = O.libm_variant()
+    # the two builds do differ: the C library's functions are not the polynomials
+    x = np.float32(0.7)
+    assert libm.lpto_log(x) != 0.0 and abs(libm.lpto_log(x) - O.lib.lpto_log(x)) < 1e-6
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, chunks * per_chunk, seed=0x5EED)
+    a = np.empty((chunks, h, w, 3))
+    b = np.empty((chunks, h, w, 3))
+    seg_a = seg_b = 0
+    for k in range(chunks):
+        u = ubos[k * per_chunk:(k + 1) * per_chunk].copy()
+        u["reset"] = 0
+        u["reset"][0] = 1
+        ia, sa = O.render_frames(cornell_oracle, u, w, h, bounces)
+        ib, sb = O.render_frames(cornell_oracle, u, w, h, bounces, library=libm)
+        assert np.all(ia[..., 3] == per_chunk) and np.all(ib[..., 3] == per_chunk)
+        a[k] = ia[..., :3].astype(np.float64) / per_chunk
+        b[k] = ib[..., :3].astype(np.float64) / per_chunk
+        seg_a += sa["segments"]
+        seg_b += sb["segments"]
+    # same seeds: nearly all paths are the same paths (the segment counts differ by a tiny fraction) ...
+    assert seg_a != seg_b or not np.array_equal(a, b)  # ... but not all: some branches did flip
+    assert abs(seg_a - seg_b) < 1e-4 * seg_a  # measured: 2e-6
+    mean_a, mean_b = a.mean(axis=0), b.mean(axis=0)
+    # image means: equal to a small fraction of a percent
+    assert abs(mean_a.mean() / mean_b.mean() - 1.0) < 5e-4  # measured: 7e-6
+    # paired test per pixel and channel over the chunks: d_k = a_k - b_k has mean zero under the hypothesis
+    d = a - b
+    sd = d.std(axis=0, ddof=1)
+    live = sd > 0  # pixels where the two builds gave different samples at all
+    z = d.mean(axis=0)[live] / (sd[live] / np.sqrt(chunks))
+    assert live.mean() > 0.1  # the test has something to look at (a pixel with a single flip gives z = +-1)
+    assert abs(z.mean()) < 0.1, z.mean()  # no systematic sign
+    assert 0.7 < z.std() < 1.5, z.std()  # Student-t with 15 degrees of freedom: 1.07
+    assert (np.abs(z) > 5.0).mean() < 2e-3
+    # and against the noise of the render itself: the difference of the two builds is far smaller than the difference
+    # of two independent halves of one build
+    half = chunks // 2
+    independent = ((a[:half].mean(axis=0) - a[half:].mean(axis=0)) ** 2).mean()
+    paired = ((mean_a - mean_b) ** 2).mean()
+    assert paired < 0.02 * independent, (paired, independent)  # measured: 3e-4
+    # relative L2 of the converged images
+    assert np.sqrt(paired * mean_a.size) / np.sqrt((mean_a ** 2).sum()) < 0.005

@@ -118,3 +118,24 @@ def test_tiny_and_degenerate_scenes_match_oracle(device, tmp_path, with_degenera
             assert device.stats().segments == st["segments"]
             assert np.array_equal(np.isnan(img), np.isnan(ref))
             assert np.array_equal(np.nan_to_num(img, nan=-1.0), np.nan_to_num(ref, nan=-1.0)), (w, h, pipeline)
+
+
+def test_zero_throughput_path_that_draws_zero_at_roulette_turns_nan(tmp_path):
+    """shaders/path_tracing.comp:317-323: `if (rand() > q) break; mask *= 1.0f / q;` — a path whose throughput
+    is exactly zero (the sky shell of the open scene is black) is dropped unless rand() returns exactly 0.0, and
+    then 0 * (1/0) makes its throughput NaN; the emission it meets afterwards makes its sample NaN.  The hash of
+    shaders/common/random.glsl:9-15 does return 0.0 now and then.  Frame 19 of the benchmark's seed sequence does
+    it at pixel (833, 634) of the 1920x1080 image: the restatement must keep that sample NaN (a renderer that
+    clamps or skips it computes a different image from the reference's), and its neighbours finite."""
+    path = str(tmp_path / "outside_synth.gltf")
+    scenes.write_outside_synth(path, 1.0)
+    s = L.Scene(path, builder=L.BUILDER_BINNED_SAH)
+    osc = O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
+    ubos = L.frame_ubos(s.camera_world, s.fov_y, 20, seed=0x5EED)
+    ubos["reset"] = 1
+    img, st = O.render_frames(osc, ubos[19:20], 1920, 1080, 8, tile=(832, 632, 8, 8), threads=1)
+    block = img[632:640, 832:840]
+    assert np.isnan(block[2, 1, :3]).all() and block[2, 1, 3] == 1.0
+    finite = np.isfinite(block[..., :3]).all(axis=2)
+    assert finite.sum() == 63
+    assert st["segments"] >= 64 + 7  # the poisoned path runs all 8 bounces: roulette never fires on a NaN throughput

@@ -29,7 +29,7 @@ def main():
             s = L.Scene(path, builder=b, device=dev if b in L.GPU_BUILDERS else None)
             build_s = time.perf_counter() - t0
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", bench_scene, "--builder", str(b),
-                                "--steps", "3", "--warmup", "1", "--spp-per-step", str(spp), "--no-cpu-baseline"],
+                                "--steps", "3", "--warmup", "1", "--spp-per-step", str(spp), "--no-cpu-baseline", "--no-secondary"],
                                capture_output=True, text=True, timeout=600)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:

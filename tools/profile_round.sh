@@ -9,8 +9,8 @@ shift || true
 EXTRA="$@"
 OUT=gpurun_out/profile_$TAG
 mkdir -p "$OUT"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 3 --warmup 1 $EXTRA > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
-SHORT="--steps 1 --warmup 0 --no-cpu-baseline $EXTRA"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 3 --warmup 1 --no-secondary $EXTRA > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
+SHORT="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary $EXTRA"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py $SHORT > "$OUT/fetch.json" 2> "$OUT/fetch.err"
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py $SHORT > "$OUT/write.json" 2> "$OUT/write.err"
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -- python3 bench.py $SHORT > "$OUT/sq.json" 2> "$OUT/sq.err"
