@@ -152,7 +152,13 @@ int lpt_set_stream(lpt_ctx* ctx, void* hip_stream);
 /* One GPUTexture (include/GPUTexture.hpp:9-13): the image and sampler created by
  * PTSceneConverter::copyTextureToGPU (src/PTSceneConverter.cpp:243-389) — one mip
  * level, RGBA8 UNORM.  Filter and address modes carry the Vulkan enum values the
- * reference passes on (vk::Filter, vk::SamplerAddressMode). */
+ * reference passes on (vk::Filter, vk::SamplerAddressMode).
+ * FORMAT: the reference creates the Vulkan image with whatever format and texel size its
+ * loader reports (image->getFormat(), image->pixelSize(), src/PTSceneConverter.cpp:248,276,348),
+ * so an sRGB or 16-bit image would be sampled as such there.  This structure has no format
+ * field: pixels are 8-bit RGBA, sampled as UNORM (texel / 255, no sRGB decode).  Callers
+ * holding any other format must convert before the upload; the host library's loader does
+ * (8-bit PNG / JPEG expanded to RGBA8), and refuses what it cannot convert. */
 typedef struct lpt_texture {
   const void* pixels;   /* width*height*4 bytes, row 0 first */
   uint32_t width, height;
@@ -225,9 +231,12 @@ int lpt_render_frame(lpt_ctx* ctx, const lpt_ubo* ubo);
  * RGBA32F sample per owned pixel slot) is a static device array of 36 MiB that every GPU the library runs
  * on holds until the process ends.  Limits: a context that owns more than 2 359 296 pixel slots (above
  * 1920x1080) gets LPT_ERR_UNSUPPORTED; lpt_upload_scene and lpt_resize (which do allocate) must have been
- * called before.  All contexts on one GPU share the array: calls on different contexts or streams of one
- * GPU must not overlap (calls on one context are ordered by its stream).  Queues its work and returns;
- * lpt_synchronize / lpt_get_stats / lpt_read_accum wait for it.  lpt_stats.extend_ms is 0 for it. */
+ * called before.  All contexts on one GPU share the array; the library puts their calls in order (a call
+ * from another context or stream first makes its stream wait for the event recorded behind the last call, which
+ * allocates nothing), so contexts need not coordinate — but such calls run one after the other, never side by
+ * side.  Under stream capture the call records no events: lpt_get_stats then has no timing for it, and the
+ * order against other users of the array between graph launches is the caller's to keep.  Queues its work and
+ * returns; lpt_synchronize / lpt_get_stats / lpt_read_accum wait for it.  lpt_stats.extend_ms is 0 for it. */
 int lpt_render_frame_static(lpt_ctx* ctx, const lpt_ubo* ubo);
 /* Blocks until all submitted work of the context has finished. */
 int lpt_synchronize(lpt_ctx* ctx);

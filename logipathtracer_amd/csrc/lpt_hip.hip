@@ -15,10 +15,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <mutex>
 #include <new>
 #include <queue>
 #include <string>
@@ -479,12 +481,19 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Partition P, const lpt_ub
 // `report` (may be null): words in host memory that receive the batch's queue fills, for the host to choose the
 // next batch's hand-over bounce by: [b] = fill of bounce b for b <= min(nBounces, kReportBounces - 1) (the queue of
 // bounce nBounces is the one handed to the persistent launch, if any), [kReportBounces] = nBounces,
-// [kReportBounces + 1] = paths started.
-constexpr uint32_t kReportBounces = 64, kReportWords = kReportBounces + 2;
+// [kReportBounces + 1] = paths started, [kReportBounces + 2] = `generation` (non-zero).  The host reads the
+// report without waiting for the stream, so it is written like a sequence lock: the generation word is cleared
+// first and set last, with system-wide fences in between, and the host takes a report only if it reads the
+// generation it expects both before and after the other words.
+constexpr uint32_t kReportBounces = 64, kReportGeneration = kReportBounces + 2, kReportWords = kReportBounces + 3;
 __global__ void k_tally(const uint32_t* __restrict__ fills, uint32_t nBounces, uint32_t timedFrom,
-                        unsigned long long* totals, uint32_t haveNext, uint32_t* report) {
+                        unsigned long long* totals, uint32_t haveNext, uint32_t* report, uint32_t generation) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long seg = 0, timed = 0, first = 0;
+    if (report) {
+      __hip_atomic_store(&report[kReportGeneration], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
     for (uint32_t b = 0; b < nBounces + haveNext; ++b) {
       unsigned long long n = 0;
       for (uint32_t r = 0; r < kCursorRegions; ++r) n += fills[b * kCursorWords + r * kCursorStride];
@@ -497,6 +506,8 @@ __global__ void k_tally(const uint32_t* __restrict__ fills, uint32_t nBounces, u
     if (report) {
       report[kReportBounces + 1] = (uint32_t)first;
       report[kReportBounces] = nBounces;
+      __threadfence_system();
+      __hip_atomic_store(&report[kReportGeneration], generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     totals[kTotPaths] += first;
     totals[kTotSegments] += seg;
@@ -665,6 +676,20 @@ __global__ void k_store_ubo(lpt_ubo value, lpt_ubo* dst) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *dst = value;
 }
 
+// Every context on a GPU shares that GPU's scratch array, and every context has a stream of its own: the calls
+// that use the array are put in order across contexts and streams.  Per GPU: an event recorded behind the last
+// call's work and who recorded it; a call from another context or stream makes its stream wait for that event
+// first (hipStreamWaitEvent: no allocation).  The events are created by lpt_create and live as long as the process.
+constexpr int kMaxStaticDevices = 64;
+struct StaticUse {
+  hipEvent_t done = nullptr;  // recorded after the last lpt_render_frame_static on this GPU
+  const void* ctx = nullptr;  // who recorded it
+  hipStream_t stream = nullptr;
+  bool recorded = false;
+};
+StaticUse g_staticUse[kMaxStaticDevices];
+std::mutex g_staticMutex;
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -735,6 +760,9 @@ struct lpt_ctx {
   volatile uint32_t* hFlags = nullptr;
   uint32_t* dFlags = nullptr;
   uint32_t traceRoundLimit = LPT_TRACE_ROUND_LIMIT;
+  // Reports of queue fills are only taken from batches of the current scene, image size and options: every
+  // change of those starts a new generation, and a report carries the generation of the batch that wrote it.
+  uint32_t reportGeneration = 1;
   unsigned char* dStatic = nullptr;  // this GPU's copy of `scratch` (device address)
 
   // timing of the last lpt_render_frames call
@@ -747,6 +775,11 @@ struct lpt_ctx {
 };
 
 namespace {
+
+// Queue-fill reports of earlier batches no longer describe what the next batch will do.
+void next_report_generation(lpt_ctx* c) {
+  if (++c->reportGeneration == 0u) c->reportGeneration = 1u;  // 0 means "being written"
+}
 
 int fail(lpt_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -1130,14 +1163,24 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (tailFixed >= 1) {
     tail = std::min<uint32_t>((uint32_t)tailFixed, nB);
   } else {
+    // A consistent copy of the last report of this generation, if there is one: the batch that wrote it has run to
+    // its end (the generation word is set last), and no later batch has begun to overwrite it (it is cleared first).
     const volatile uint32_t* rep = c->hFlags + 4;
-    const uint32_t repBounces = rep[kReportBounces], repPaths = rep[kReportBounces + 1];
+    uint32_t copy[kReportWords];
+    bool have = rep[kReportGeneration] == c->reportGeneration;
+    if (have) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (uint32_t k = 0; k < kReportWords; ++k) copy[k] = rep[k];
+      std::atomic_thread_fence(std::memory_order_acquire);
+      have = rep[kReportGeneration] == c->reportGeneration;
+    }
+    const uint32_t repBounces = have ? copy[kReportBounces] : 0u, repPaths = have ? copy[kReportBounces + 1] : 0u;
     if (repBounces >= 1u && repPaths > 0u) {
       constexpr double kShortQueue = 1024.0 * 1024.0;
       const double scale = (double)paths / (double)repPaths;
       const uint32_t known = std::min(std::min(repBounces, kReportBounces - 1u), nB - 1u);  // fills [0, known] are reported
       for (uint32_t b = 1; b <= known; ++b)
-        if ((double)rep[b] * scale < kShortQueue) {
+        if ((double)copy[b] * scale < kShortQueue) {
           tail = b;
           break;
         }
@@ -1172,7 +1215,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
                      (uint32_t)frames, c->dSamples, c->dAccum);
   // segments of the bounces run here; the persistent launch has added those it traced
   hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, tail, primary_packets() ? 1u : 0u, c->dTotals,
-                     tail < nB ? 1u : 0u, c->dFlags + 4);
+                     tail < nB ? 1u : 0u, c->dFlags + 4, c->reportGeneration);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -1266,7 +1309,7 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                      (uint32_t)frames, c->dSamples, c->dAccum);
   // camera paths and their segments; the persistent launch has added the segments it traced
-  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, 1u, 1u, c->dTotals, 0u, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, c->stream, c->dCounts, 1u, 1u, c->dTotals, 0u, (uint32_t*)nullptr, 0u);
   LPT_HIP(c, hipGetLastError());
   return 0;
 }
@@ -1328,6 +1371,7 @@ int set_partition(lpt_ctx* c, int W, int H, int tileW, int tileH, int rank, int 
   LPT_HIP(c, hipMemsetAsync(c->dAccum, 0, slots * sizeof(float4), c->stream));
   c->part = P;
   c->sized = true;
+  next_report_generation(c);
   return 0;
 }
 
@@ -1387,6 +1431,12 @@ int lpt_create(int device, lpt_ctx** out) {
   // this GPU's copy of the static scratch array (the device is current here)
   if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&c->dStatic), HIP_SYMBOL(scratch))) != hipSuccess)
     return bail("hipGetSymbolAddress(scratch)", e);
+  if (device < kMaxStaticDevices) {  // the event that orders this GPU's users of the array
+    std::lock_guard<std::mutex> lock(g_staticMutex);
+    if (!g_staticUse[device].done &&
+        (e = hipEventCreateWithFlags(&g_staticUse[device].done, hipEventDisableTiming)) != hipSuccess)
+      return bail("hipEventCreate", e);
+  }
   void* flags = nullptr;
   if ((e = hipHostMalloc(&flags, (4 + kReportWords) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
     return bail("hipHostMalloc", e);
@@ -1402,6 +1452,10 @@ void lpt_destroy(lpt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->device < kMaxStaticDevices) {  // its work on the static scratch is done; the record must not outlive it
+    std::lock_guard<std::mutex> lock(g_staticMutex);
+    if (g_staticUse[c->device].ctx == c) g_staticUse[c->device] = StaticUse{g_staticUse[c->device].done, nullptr, nullptr, false};
+  }
   free_scene(c);
   free_textures(c);
   free_pool(c);
@@ -1698,6 +1752,7 @@ int lpt_upload_scene(lpt_ctx* c, const lpt_object* objects, uint32_t nObj, const
   c->nObjects = nObj;
   c->stackNeed = stackNeed;
   c->sceneLoaded = true;
+  next_report_generation(c);
   return LPT_OK;
 }
 
@@ -1727,6 +1782,9 @@ int lpt_set_options(lpt_ctx* c, int max_bounces, int bsdf_mode, int pipeline, in
       pipeline != LPT_PIPELINE_AUTO && pipeline != LPT_PIPELINE_HYBRID)
     return fail(c, LPT_ERR_INVALID, "bad pipeline");
   if (frames_in_flight < 0 || frames_in_flight > 4096) return fail(c, LPT_ERR_INVALID, "bad frames_in_flight");
+  if (c->maxBounces != max_bounces || c->bsdfMode != bsdf_mode || c->pipeline != pipeline ||
+      c->framesInFlight != frames_in_flight)
+    next_report_generation(c);
   c->maxBounces = max_bounces;
   c->bsdfMode = bsdf_mode;
   c->pipeline = pipeline;
@@ -1808,7 +1866,16 @@ int lpt_render_frame_static(lpt_ctx* c, const lpt_ubo* ubo) {
                 "lpt_render_frame_static: the context owns " + std::to_string(c->part.nSlots) + " pixel slots, the static "
                 "scratch holds " + std::to_string(kStaticMaxSlots) + " (1920x1080); use lpt_render_frame");
   if (!c->dStatic) return fail(c, LPT_ERR_HIP, "static scratch address unknown");
+  if (c->device >= kMaxStaticDevices) return fail(c, LPT_ERR_UNSUPPORTED, "lpt_render_frame_static: device index beyond 63");
   LPT_USE_DEVICE(c);
+  // Under stream capture nothing may be recorded that the host reads back later (timing events), and the order
+  // against other users of the array is the caller's to keep between graph launches.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(c->stream, &capture) != hipSuccess) {
+    (void)hipGetLastError();
+    capture = hipStreamCaptureStatusNone;
+  }
+  const bool capturing = capture != hipStreamCaptureStatusNone;
   // everything below is stream-ordered work on memory that exists already: the static array (cursors,
   // uniform block, samples), the context's counters and the accumulation image
   uint32_t* cursor = reinterpret_cast<uint32_t*>(c->dStatic);
@@ -1817,18 +1884,30 @@ int lpt_render_frame_static(lpt_ctx* c, const lpt_ubo* ubo) {
   c->evUsed = 0;
   c->haveTiming = false;
   c->activePipeline = LPT_PIPELINE_PERSISTENT;
+  c->timedLo = 0u;
+  c->timedHi = (uint32_t)c->maxBounces;
+  std::lock_guard<std::mutex> lock(g_staticMutex);  // one call at a time enqueues work on this GPU's array
+  StaticUse& use = g_staticUse[c->device];
+  if (!capturing && use.recorded && (use.ctx != c || use.stream != c->stream))
+    LPT_HIP(c, hipStreamWaitEvent(c->stream, use.done, 0));  // behind the last call of another context or stream
   LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long), c->stream));
   LPT_HIP(c, hipMemsetAsync(cursor, 0, kCursorWords * sizeof(uint32_t), c->stream));  // the last call's cursors
-  LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
+  if (!capturing) LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
   hipLaunchKernelGGL(k_store_ubo, dim3(1), dim3(64), 0, c->stream, *ubo, dUbo);
   if (c->nValid)
     dispatch_trace<false>(c, 1, cursor, TraceQueue{nullptr, nullptr, nullptr, QueueFill{nullptr, 0u}, 0u, 1u}, dUbo, samples);
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(c, c->part.nSlots, 8)), dim3(kBlock), 0, c->stream, c->part, dUbo, 1u,
                      samples, c->dAccum);
   LPT_HIP(c, hipGetLastError());
-  LPT_HIP(c, hipEventRecord(c->evStop, c->stream));
-  c->lastFrames = 1;
-  c->haveTiming = true;
+  if (!capturing) {
+    LPT_HIP(c, hipEventRecord(c->evStop, c->stream));
+    LPT_HIP(c, hipEventRecord(use.done, c->stream));
+    use.ctx = c;
+    use.stream = c->stream;
+    use.recorded = true;
+    c->lastFrames = 1;
+    c->haveTiming = true;
+  }
   return LPT_OK;
 }
 

@@ -51,6 +51,21 @@ def test_static_entry_point_equals_render_frame(cornell):
         want, _ = _frames(a, ubos, static=False)
         got, _ = _frames(b, ubos, static=True)
         assert np.array_equal(got, want) and (got[..., 3] > 0).any()
+        # two contexts on one GPU, each with a stream of its own, share the array: their calls are put in order
+        # (hipStreamWaitEvent on the event of the last user), so frames enqueued back to back without any host-side
+        # wait in between come out as if each context had the array to itself
+        for dev in (a, b):
+            dev.resize(640, 360)  # large enough for the launches of the two contexts to overlap if nothing ordered them
+        want, wst = _frames(a, ubos, static=False)
+        for dev in (a, b):
+            dev.resize(640, 360)  # clears the images
+        for i in range(len(ubos)):
+            a.render_frame_static(ubos[i:i + 1])
+            b.render_frame_static(ubos[i:i + 1])
+        got_a, got_b = a.read_accum(), b.read_accum()
+        assert np.array_equal(got_a, want) and np.array_equal(got_b, want)
+        st = b.stats()
+        assert st.paths == 640 * 360 and (st.timed_bounce_lo, st.timed_bounce_hi) == (0, bounces)
         # beyond the static array's size the call refuses instead of allocating
         b.resize(2048, 1160)
         with pytest.raises(L.LptError, match="static") as e:
