@@ -195,8 +195,13 @@ __device__ __forceinline__ float union_area(const float* __restrict__ nodeMin, c
 }
 
 // nn[i] = the position j in [i-r, i+r], j != i, whose cluster forms the smallest box with cluster i.  Pairs
-// are ranked by (area, lower position, higher position): a total order that both members of a pair see
-// alike, so the best pair of the whole list always chooses each other and every round merges something.
+// are ranked by a key that both members of a pair compute alike — (area, distance |i - j|, parity of the lower
+// position, lower position) — a total order, so the best pair of the whole list always chooses each other and
+// every round merges something.  The order among equal areas matters when many areas are equal (coincident
+// triangles, triangles on one axis line, extents whose products underflow to 0 or overflow to infinity): nearest
+// first, and among the two nearest the pair that starts at an even position, makes the pairs (2k, 2k+1) choose
+// each other, so such a list halves every round.  (Ranked by position alone, every cluster would choose the lowest
+// position of its window, only the pair (0, 1) would be mutual, and the build would take one round per triangle.)
 __global__ void k_ploc_nearest(const uint32_t* __restrict__ cid, uint32_t m, const float* __restrict__ nodeMin,
                                const float* __restrict__ nodeMax, uint32_t* __restrict__ nn) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,19 +210,31 @@ __global__ void k_ploc_nearest(const uint32_t* __restrict__ cid, uint32_t m, con
   const uint32_t lo = i > (uint32_t)kPlocRadius ? i - kPlocRadius : 0u;
   const uint32_t hi = min(m - 1u, i + (uint32_t)kPlocRadius);
   float best = INFINITY;
-  uint32_t bestJ = i + 1u < m ? i + 1u : i - 1u;  // some neighbour even if every area is NaN
-  uint32_t bestLo = min(i, bestJ), bestHi = max(i, bestJ);
+  // some neighbour even if every area is NaN: the other member of the pair (2k, 2k+1) where there is one
+  uint32_t bestJ = (i ^ 1u) < m ? (i ^ 1u) : i - 1u;
+  uint32_t bestLo = min(i, bestJ), bestDist = 1u;
   bool have = false;
   for (uint32_t j = lo; j <= hi; ++j) {
     if (j == i) continue;
     const float a = union_area(nodeMin, nodeMax, me, cid[j]);
-    const uint32_t pl = min(i, j), ph = max(i, j);
-    const bool better = !have ? (a == a) : (a < best || (a == best && (pl < bestLo || (pl == bestLo && ph < bestHi))));
+    const uint32_t pl = min(i, j), dist = max(i, j) - pl;
+    bool better;
+    if (!have) {
+      better = a == a;
+    } else if (a != best) {
+      better = a < best;
+    } else if (dist != bestDist) {
+      better = dist < bestDist;
+    } else if ((pl & 1u) != (bestLo & 1u)) {
+      better = (pl & 1u) == 0u;
+    } else {
+      better = pl < bestLo;
+    }
     if (better) {
       best = a;
       bestJ = j;
       bestLo = pl;
-      bestHi = ph;
+      bestDist = dist;
       have = true;
     }
   }
@@ -270,6 +287,17 @@ __global__ void k_ploc_merge(const uint32_t* __restrict__ cid, const uint32_t* _
   out[validRank[i]] = id;
 }
 
+// The four numbers the host needs after a round's scans, in one place: how many pairs merge and how many
+// clusters survive are the last rank plus the last flag of each scan.
+__global__ void k_ploc_tail(const uint32_t* __restrict__ leaderRank, const uint32_t* __restrict__ leader,
+                            const uint32_t* __restrict__ validRank, const uint32_t* __restrict__ valid, uint32_t m,
+                            uint32_t* __restrict__ out /* [2]: merges, survivors */) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = leaderRank[m - 1u] + leader[m - 1u];
+    out[1] = validRank[m - 1u] + valid[m - 1u];
+  }
+}
+
 __global__ void k_ploc_init(uint32_t* __restrict__ cid, uint32_t n) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) cid[j] = n - 1u + j;  // leaf ids, in Morton order
@@ -304,13 +332,14 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
   uint32_t *dBounds = nullptr, *dCodes = nullptr, *dIds = nullptr, *dCodesS = nullptr, *dIdsS = nullptr;
   uint32_t *dLeft = nullptr, *dRight = nullptr, *dLo = nullptr, *dHi = nullptr, *dReadyA = nullptr, *dReadyB = nullptr;
   uint32_t* dRemaining = nullptr;
+  uint32_t* dRemaining2 = nullptr;  // the two words a clustering round reports
   void* dTemp = nullptr;
   uint32_t *dCidA = nullptr, *dCidB = nullptr, *dNn = nullptr, *dLeader = nullptr, *dValid = nullptr, *dLeaderRank = nullptr,
            *dValidRank = nullptr;
   void* dScanTemp = nullptr;
   auto release = [&]() {
     void* ptrs[] = {dPos, dBoxMin, dBoxMax, dNodeMin, dNodeMax, dBounds, dCodes, dIds, dCodesS, dIdsS,
-                    dLeft, dRight, dLo, dHi, dReadyA, dReadyB, dRemaining, dTemp,
+                    dLeft, dRight, dLo, dHi, dReadyA, dReadyB, dRemaining, dRemaining2, dTemp,
                     dCidA, dCidB, dNn, dLeader, dValid, dLeaderRank, dValidRank, dScanTemp};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -366,6 +395,7 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
     LB_HIP(ctx, hipMalloc(&dValid, n * sizeof(uint32_t)));
     LB_HIP(ctx, hipMalloc(&dLeaderRank, n * sizeof(uint32_t)));
     LB_HIP(ctx, hipMalloc(&dValidRank, n * sizeof(uint32_t)));
+    LB_HIP(ctx, hipMalloc(&dRemaining2, 2 * sizeof(uint32_t)));
     size_t scanBytes = 0;
     LB_HIP(ctx, rocprim::exclusive_scan(nullptr, scanBytes, dLeader, dLeaderRank, 0u, n, rocprim::plus<uint32_t>(), stream));
     LB_HIP(ctx, hipMalloc(&dScanTemp, std::max<size_t>(scanBytes, 16)));
@@ -374,27 +404,29 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
     uint32_t* cur = dCidA;
     uint32_t* nxt = dCidB;
     for (int round = 0; m > 1; ++round) {
-      if (round > 8192) {
+      if (round > 4096) {  // every round removes at least one cluster in 4 * radius: about 64 ln(n) rounds at worst
         release();
         return lpt_internal_fail(ctx, LPT_ERR_INVALID, "PLOC clustering did not converge");
       }
       const dim3 grid((m + B - 1) / B);
       hipLaunchKernelGGL(k_ploc_nearest, grid, dim3(B), 0, stream, cur, m, dNodeMin, dNodeMax, dNn);
-      uint32_t tail[4] = {0, 0, 0, 0};  // last leader rank and flag, last valid rank and flag
+      // A round that would merge fewer than one cluster in 4 * radius (possible only when nearly all candidate
+      // boxes are non-finite, so that hardly any two clusters choose each other) pairs neighbours instead: the
+      // number of rounds stays logarithmic whatever the input.
+      uint32_t tail[2] = {0, 0};  // merges, survivors
       for (int pairUp = 0; pairUp < 2; ++pairUp) {
         if (pairUp) hipLaunchKernelGGL(k_ploc_pair_up, grid, dim3(B), 0, stream, dNn, m);
         hipLaunchKernelGGL(k_ploc_flags, grid, dim3(B), 0, stream, dNn, m, dLeader, dValid, 0);
         LB_HIP(ctx, hipGetLastError());
         LB_HIP(ctx, rocprim::exclusive_scan(dScanTemp, scanBytes, dLeader, dLeaderRank, 0u, m, rocprim::plus<uint32_t>(), stream));
         LB_HIP(ctx, rocprim::exclusive_scan(dScanTemp, scanBytes, dValid, dValidRank, 0u, m, rocprim::plus<uint32_t>(), stream));
-        LB_HIP(ctx, hipMemcpyAsync(&tail[0], dLeaderRank + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LB_HIP(ctx, hipMemcpyAsync(&tail[1], dLeader + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LB_HIP(ctx, hipMemcpyAsync(&tail[2], dValidRank + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        LB_HIP(ctx, hipMemcpyAsync(&tail[3], dValid + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(64), 0, stream, dLeaderRank, dLeader, dValidRank, dValid, m, dRemaining2);
+        LB_HIP(ctx, hipGetLastError());
+        LB_HIP(ctx, hipMemcpyAsync(tail, dRemaining2, sizeof tail, hipMemcpyDeviceToHost, stream));
         LB_HIP(ctx, hipStreamSynchronize(stream));
-        if (tail[0] + tail[1] > 0) break;  // something merges; otherwise (non-finite boxes only) pair up neighbours
+        if ((uint64_t)tail[0] * 4u * (uint32_t)kPlocRadius >= m) break;
       }
-      const uint32_t merges = tail[0] + tail[1], survivors = tail[2] + tail[3];
+      const uint32_t merges = tail[0], survivors = tail[1];
       if (merges == 0 || survivors != m - merges || nextId + merges > nInternal) {
         release();
         return lpt_internal_fail(ctx, LPT_ERR_INVALID, "PLOC clustering made no progress");

@@ -50,11 +50,17 @@ struct BitReader {
   uint32_t acc = 0;
   int n = 0;
   bool atMarker = false;
+  int padded = 0;  // zero bytes fed behind the end of the entropy-coded data
 
+  // Behind the end of the data (a marker, or the end of the file) the reader feeds zero bits: a well-formed scan
+  // never consumes them, it only looks up to four bytes ahead.  A scan that goes on decoding from them is cut
+  // off after eight bytes' worth, so that the work of a scan stays proportional to the bytes it really has.
   void fill() {
     while (n <= 24) {
       uint32_t b = 0;
-      if (!atMarker && p < end) {
+      if (atMarker || p >= end) {
+        if (++padded > 8) bad("entropy-coded data ends before the scan does");
+      } else {
         b = *p;
         if (b == 0xFF) {
           if (p + 1 < end && p[1] == 0x00) {
@@ -100,6 +106,7 @@ struct BitReader {
     acc = 0;
     n = 0;
     atMarker = false;
+    padded = 0;
     while (p < end && *p != 0xFF) ++p;        // (a well-formed file has nothing here)
     while (p + 1 < end && p[1] == 0xFF) ++p;  // fill bytes
     if (p + 1 >= end || p[1] != (uint8_t)(0xD0 + m)) bad("restart marker missing or out of sequence");
@@ -161,6 +168,7 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
   int restartInterval = 0;
   int adobeTransform = -1;
   bool haveFrame = false, ended = false, progressive = false;
+  int scans = 0;
 
   size_t pos = 2;
   while (!ended) {
@@ -217,6 +225,10 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
       const int nf = seg[5];
       if (X == 0 || Y == 0) bad("image without size (DNL marker) is not supported");
       if (X > 32768 || Y > 32768) bad("image size outside 1..32768");
+      // Memory and time are tied to the size of the file, not to what a header claims: 64 Mi pixels at most, and
+      // no more than 4096 pixels per byte of file (real files hold tens of pixels per byte at their smallest).
+      if ((long long)X * Y > (64ll << 20)) bad("image of more than 64 Mi pixels");
+      if ((long long)X * Y > 4096ll * (long long)size) bad("frame header claims more pixels than a file of this size can hold");
       if (nf != 1 && nf != 3) bad(nf == 4 ? "four-component (CMYK) images are not supported" : "bad component count");
       if (segLen < 6 + 3 * (size_t)nf) bad("truncated frame header");
       comps.resize((size_t)nf);
@@ -253,6 +265,7 @@ void decodeJPEG(const uint8_t* data, size_t size, std::vector<uint8_t>& rgba, ui
       if (segLen >= 12 && std::memcmp(seg, "Adobe", 5) == 0) adobeTransform = seg[11];
     } else if (marker == 0xDA) {  // scan
       if (!haveFrame) bad("scan before the frame header");
+      if (++scans > 256) bad("more than 256 scans");  // progressive files in the wild have about ten
       if (segLen < 1) bad("truncated scan header");
       const int ns = seg[0];
       if (ns < 1 || ns > (int)comps.size() || segLen < 1 + 2 * (size_t)ns + 3) bad("bad scan header");

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <new>
 #include <stdexcept>
 
 #include "minijson.hpp"
@@ -294,6 +295,8 @@ Ref<Image> loadImage(Doc& d, size_t index) {
     else decodePNG(raw, bytes.size(), img->pixels_, img->width_, img->height_);
   } catch (const std::runtime_error& e) {
     throw std::runtime_error("glTF: image " + std::to_string(index) + " ('" + img->uri + "'): " + e.what());
+  } catch (const std::bad_alloc&) {
+    throw std::runtime_error("glTF: image " + std::to_string(index) + " ('" + img->uri + "'): not enough memory to decode it");
   }
   d.images[index] = img;
   return img;

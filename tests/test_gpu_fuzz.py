@@ -393,3 +393,45 @@ def test_gpu_builders_keep_their_shape_on_hostile_triangles(device, which):
             else:
                 stack += [a, b]
         assert np.all(seen == 1), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1], ids=["lbvh", "ploc"])
+def test_gpu_builders_stay_logarithmic_on_many_equal_boxes(device, which):
+    """20 000 identical triangles, 20 000 triangles along one axis line (all merged boxes have area 0), and extents
+    whose products underflow to 0 or overflow to infinity: every candidate pair of the clustering builder then has
+    the same area.  The build must succeed in a number of rounds that does not grow with the triangle count (seen
+    here as a balanced tree: a builder that merged one pair per round would return a chain 20 000 deep, or give up)."""
+    import time
+    n = 20000
+    one = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], dtype=np.float32)
+    cases = {"identical": np.broadcast_to(one, (n, 3, 3)).copy()}
+    c = np.zeros((n, 3, 3), dtype=np.float32)
+    c[:, :, 0] = (np.arange(n, dtype=np.float32)[:, None] + np.array([0.0, 0.4, 0.8], dtype=np.float32)[None, :])
+    cases["on one axis line"] = c
+    rng = np.random.default_rng(9)
+    cases["extents that underflow"] = (rng.uniform(0, 1, size=(n, 3, 3)) * 1e-25).astype(np.float32)
+    cases["extents that overflow"] = (rng.uniform(-1, 1, size=(n, 3, 3)) * 3e25).astype(np.float32)
+    for name, corners in cases.items():
+        t0 = time.perf_counter()
+        nodes, order = device.build_mesh_bvh(corners, which)
+        dt = time.perf_counter() - t0
+        assert sorted(order.tolist()) == list(range(n)), name
+        depth, worst, covered = {0: 1}, 1, 0
+        stack = [0]
+        while stack:
+            i = stack.pop()
+            nd = nodes[i]
+            a, b = int(nd["indices"][0]), int(nd["indices"][1])
+            if nd["isLeaf"]:
+                assert 0 < b - a <= 4, name
+                covered += b - a
+            else:
+                for ch in (a, b):
+                    depth[ch] = depth[i] + 1
+                    worst = max(worst, depth[ch])
+                    stack.append(ch)
+        assert covered == n, name
+        if which == 1:
+            assert worst <= 40, (name, worst)  # log2(20000 / 4) is 12.3
+        assert dt < 20.0, (name, dt)

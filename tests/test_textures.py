@@ -6,6 +6,7 @@ V axis).  GPU: parity of a scene that uses every slot, filter and wrap mode with
 filtering follows the fixed formula of the arithmetic contract; a Vulkan device's own filtering is not
 reproduced bit for bit ("parity unpinned" for textured materials)."""
 import os
+import shutil
 
 import numpy as np
 import pytest
@@ -365,3 +366,64 @@ def test_command_line_renderer_writes_the_same_image(textured, tmp_path, device)
     g.write(str(tmp_path / "readback.gltf"))
     back = L.Scene(str(tmp_path / "readback.gltf")).textures[0]["pixels"]
     assert back.shape == (h, w, 4) and np.array_equal(back[..., :3], ppm) and np.all(back[..., 3] == 255)
+
+
+def _jpeg_segments(data):
+    """(marker, start, end) of every marker segment up to the first scan; `end` of a scan header segment is where its
+    entropy-coded data begins."""
+    out, pos = [], 2
+    while pos + 4 <= len(data):
+        assert data[pos] == 0xFF
+        marker = data[pos + 1]
+        length = (data[pos + 2] << 8) | data[pos + 3]
+        out.append((marker, pos, pos + 2 + length))
+        if marker == 0xDA:
+            break
+        pos += 2 + length
+    return out
+
+
+def test_jpeg_resource_use_is_tied_to_the_file_size(tmp_path):
+    """A few hundred bytes must not be able to claim gigabytes or hours: frame headers are held to a pixel budget, a scan
+    that runs out of entropy-coded data is cut off instead of decoding zero bits for the rest of the image, and the
+    number of scans is bounded."""
+    base = open(os.path.join(GOLDEN, "jpeg_444.jpg"), "rb").read()
+    sof = [s for s in _jpeg_segments(base) if s[0] == 0xC0][0]
+
+    def with_size(width, height):
+        d = bytearray(base)
+        d[sof[1] + 5:sof[1] + 9] = bytes([height >> 8, height & 255, width >> 8, width & 255])
+        return bytes(d)
+
+    # 32768 x 32768 claimed by a small file
+    open(str(tmp_path / "huge.jpg"), "wb").write(with_size(32768, 32768))
+    with pytest.raises(L.LptError, match="JPEG.*(64 Mi pixels|more pixels than a file of this size)"):
+        _one_texture_scene(tmp_path, "huge.jpg")
+    # within the 64 Mi budget but far beyond what the file's bytes could hold
+    open(str(tmp_path / "claim.jpg"), "wb").write(with_size(8000, 8000))
+    with pytest.raises(L.LptError, match="JPEG.*more pixels than a file of this size"):
+        _one_texture_scene(tmp_path, "claim.jpg")
+    # a frame four times the real one, inside every budget: the scan runs out of data
+    w0 = (base[sof[1] + 7] << 8) | base[sof[1] + 8]
+    h0 = (base[sof[1] + 5] << 8) | base[sof[1] + 6]
+    open(str(tmp_path / "short.jpg"), "wb").write(with_size(2 * w0, 2 * h0))
+    with pytest.raises(L.LptError, match="JPEG.*(ends before the scan does|no Huffman code|out of range|beyond the block)"):
+        _one_texture_scene(tmp_path, "short.jpg")
+    # a progressive file with 300 more scans, each well-formed and complete (a refinement of the DC bit that is
+    # already final: one zero bit per block)
+    prog = open(os.path.join(GOLDEN, "jpeg_progressive_grey.jpg"), "rb").read()
+    assert prog.endswith(b"\xff\xd9")
+    sof2 = [s for s in _jpeg_segments(prog) if s[0] == 0xC2][0]
+    ph, pw = (prog[sof2[1] + 5] << 8) | prog[sof2[1] + 6], (prog[sof2[1] + 7] << 8) | prog[sof2[1] + 8]
+    comp_id = prog[sof2[1] + 10]
+    blocks = ((pw + 7) // 8) * ((ph + 7) // 8)
+    scan = b"\xff\xda" + bytes([0, 8, 1, comp_id, 0x00, 0, 0, 0x10]) + b"\0" * ((blocks + 7) // 8)
+    open(str(tmp_path / "few.jpg"), "wb").write(prog[:-2] + scan * 3 + b"\xff\xd9")
+    assert len(_one_texture_scene(tmp_path, "few.jpg").textures) == 1  # a few such scans are fine
+    open(str(tmp_path / "scans.jpg"), "wb").write(prog[:-2] + scan * 300 + b"\xff\xd9")
+    with pytest.raises(L.LptError, match="JPEG.*more than 256 scans"):
+        _one_texture_scene(tmp_path, "scans.jpg")
+    # the untouched files still load
+    for name in ("jpeg_444.jpg", "jpeg_progressive_grey.jpg"):
+        shutil.copy(os.path.join(GOLDEN, name), str(tmp_path / name))
+        assert len(_one_texture_scene(tmp_path, name).textures) == 1
