@@ -2,6 +2,7 @@
 // Every function catches C++ exceptions and reports them through an error string.
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -28,7 +29,8 @@ struct RendererHandle {
   lsg::Ref<lsg::Scene> scene;
   // loadScene on a thread of its own, as src/Main.cpp:45 runs it
   std::thread loadThread;
-  int loadStatus = 0;
+  std::atomic<bool> loadRunning{false};  // set by the starter, cleared by the thread as its last step
+  int loadStatus = 0;                    // written by the thread before it clears loadRunning, read after a join
   std::string loadError;
   ~RendererHandle() {
     if (loadThread.joinable()) loadThread.join();
@@ -169,16 +171,19 @@ int lpth_renderer_load_gltf(void* r, const char* path, int builder) {
 int lpth_renderer_load_gltf_async(void* r, const char* path, int builder) {
   return guarded([&] {
     auto* h = (RendererHandle*)r;
-    if (h->loadThread.joinable()) throw std::runtime_error("a load is already running");
+    if (h->loadRunning.load()) throw std::runtime_error("a load is already running");
+    if (h->loadThread.joinable()) h->loadThread.join();  // a finished load nobody has waited for
     h->loadStatus = 0;
     h->loadError.clear();
     std::string file(path);
+    h->loadRunning = true;
     h->loadThread = std::thread([h, file, builder] {
       try {
         lsg::GLTFLoader loader;
-        h->scene = loader.load(file).at(0);
+        lsg::Ref<lsg::Scene> scene = loader.load(file).at(0);
         h->renderer->setMeshBuilder((PTSceneConverter::MeshBuilder)builder);
-        h->renderer->loadScene(h->scene);
+        h->renderer->loadScene(scene);
+        h->scene = scene;  // (the previous scene is let go of only once the new one is in place)
       } catch (const std::exception& e) {
         h->loadStatus = -1;
         h->loadError = e.what();
@@ -186,6 +191,7 @@ int lpth_renderer_load_gltf_async(void* r, const char* path, int builder) {
         h->loadStatus = -1;
         h->loadError = "unknown C++ exception";
       }
+      h->loadRunning = false;
     });
   });
 }

@@ -4,6 +4,7 @@
 #include <ctime>
 #include <iostream>
 #include <stdexcept>
+#include <thread>
 
 RendererPT::RendererPT(const cppglfw::Window& window, const RendererConfiguration& configuration)
     : RendererCore(window, configuration), rand_((uint32_t)std::time(nullptr)), sceneConverter_(device_) {
@@ -21,11 +22,13 @@ void RendererPT::applyOptions() {
 }
 
 void RendererPT::setDeferredFrames(uint32_t n) {
+  Lock lock(frameMutex_);
   flush();
   deferredFrames_ = n == 0 ? 1u : n;
 }
 
 void RendererPT::flush() {
+  Lock lock(frameMutex_);
   if (batching_ || pending_.empty()) return;
   // the queue is emptied first: a failing batch must not be submitted again by the next flush
   std::vector<PathTracerUBO> frames;
@@ -34,18 +37,21 @@ void RendererPT::flush() {
 }
 
 void RendererPT::setMaxTraceDepth(int bounces) {
+  Lock lock(frameMutex_);
   flush();  // frames queued so far were drawn under the old options
   maxTraceDepth_ = bounces;
   applyOptions();
 }
 
 void RendererPT::setBsdfMode(int mode) {
+  Lock lock(frameMutex_);
   flush();
   bsdfMode_ = mode;
   applyOptions();
 }
 
 void RendererPT::setPipeline(int pipeline, int framesInFlight) {
+  Lock lock(frameMutex_);
   flush();
   pipeline_ = pipeline;
   framesInFlight_ = framesInFlight;
@@ -53,7 +59,8 @@ void RendererPT::setPipeline(int pipeline, int framesInFlight) {
 }
 
 void RendererPT::loadScene(const lsg::Ref<lsg::Scene>& scene) {
-  sceneLoaded_ = false;
+  sceneLoaded_ = false;  // from here on drawFrame does nothing (and does not wait for the mutex below)
+  Lock lock(frameMutex_);  // a frame being drawn right now finishes first
   flush();  // frames of the previous scene still queued
 
   sceneConverter_.loadScene(scene);
@@ -76,6 +83,7 @@ void RendererPT::loadScene(const lsg::Ref<lsg::Scene>& scene) {
 }
 
 void RendererPT::onSwapChainRecreate() {
+  Lock lock(frameMutex_);
   // a new target size restarts accumulation (src/RendererPT.cpp:225-232); frames still queued belonged to
   // the old image and are dropped with it
   pending_.clear();
@@ -125,12 +133,26 @@ void RendererPT::postDraw() {
   }
 }
 
+bool RendererPT::lockForDrawing(std::unique_lock<std::recursive_mutex>& lock) {
+  // A load holds the mutex for seconds and has cleared the flag before taking it: give up then, wait otherwise
+  // (another thread reading the image or changing an option is done in a moment).
+  while (!lock.try_lock()) {
+    if (!sceneLoaded_) return false;
+    std::this_thread::yield();
+  }
+  return sceneLoaded_;
+}
+
 void RendererPT::drawFrame() {
-  if (sceneLoaded_) RendererCore::drawFrame();
+  if (!sceneLoaded_) return;
+  std::unique_lock<std::recursive_mutex> lock(frameMutex_, std::defer_lock);
+  if (lockForDrawing(lock)) RendererCore::drawFrame();
 }
 
 void RendererPT::drawFrames(uint32_t n) {
   if (!sceneLoaded_ || n == 0) return;
+  std::unique_lock<std::recursive_mutex> lock(frameMutex_, std::defer_lock);
+  if (!lockForDrawing(lock)) return;
   flush();
   batching_ = true;
   try {
@@ -144,12 +166,14 @@ void RendererPT::drawFrames(uint32_t n) {
 }
 
 void RendererPT::readAccumulation(std::vector<float>& rgba) {
+  Lock lock(frameMutex_);
   flush();
   rgba.resize((size_t)renderWidth_ * renderHeight_ * 4);
   check(lpt_read_accum(device_, rgba.data()), "lpt_read_accum");
 }
 
 void RendererPT::resolve(std::vector<float>& rgba) {
+  Lock lock(frameMutex_);
   flush();
   rgba.resize((size_t)renderWidth_ * renderHeight_ * 4);
   // the display pass divides by the number of samples accumulated so far

@@ -5,6 +5,7 @@
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "glibc_rand.hpp"
@@ -16,7 +17,11 @@ class RendererPT : public RendererCore {
   RendererPT(const cppglfw::Window& window, const RendererConfiguration& configuration);
 
   // May run on another thread than drawFrame (src/Main.cpp:45); drawFrame does nothing
-  // until loading has finished.
+  // until loading has finished.  The reference guards this with one atomic flag only
+  // (include/RendererPT.h:87); here the flag says "nothing to draw" and a mutex keeps the two
+  // threads out of the frame queue and the device context at the same time: loadScene holds it
+  // from its first to its last step, every other entry point for its own duration, and a
+  // drawFrame that finds it taken by a load returns at once.
   void loadScene(const lsg::Ref<lsg::Scene>& scene) override;
 
   void drawFrame() override;
@@ -84,6 +89,12 @@ class RendererPT : public RendererCore {
   std::chrono::time_point<std::chrono::high_resolution_clock> startTime_;
 
   std::atomic<bool> sceneLoaded_{false};
+  // guards pending_, the frame counters and every call on device_; recursive: the setters, drawFrames and the
+  // readers flush the queue from inside
+  std::recursive_mutex frameMutex_;
+  using Lock = std::lock_guard<std::recursive_mutex>;
+  // takes frameMutex_ unless a scene is being loaded; false = nothing to draw now
+  bool lockForDrawing(std::unique_lock<std::recursive_mutex>& lock);
   lsg::Ref<lsg::Transform> selectedCameraTransform_;
   PTSceneConverter sceneConverter_;
 };
