@@ -3,8 +3,11 @@
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the bench command
   profiles/<tag>_pmc.txt            per-kernel PMC totals and derived ratios
-  profiles/trace_traffic.json, extend_traffic.json   HBM bytes per k_trace / k_extend launch, read by
-                                    bench.py (roofline.traffic)
+  profiles/<tag>_traffic_<key>.json HBM bytes per launch of the dominant kernel of the profiled workload (k_extend
+                                    or k_trace), read by bench.py for roofline.traffic / roofline.hbm; <key> names
+                                    the workload as bench.py's workload_key does (e.g. cornell_1920x1080_8b)
+
+  usage: tools/profile_digest.py <tag> [<key>]      (tag may carry a suffix: r03_outside -> profiles/r03_outside_*)
 
 HBM bytes follow the gfx950 rule for rocprofv3: FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE counts
 128-byte read requests as 64 bytes, so reads are doubled: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -22,6 +25,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pmc_summary  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+key = sys.argv[2] if len(sys.argv) > 2 else "cornell_1920x1080_8b"
+round_tag = tag.split("_")[0]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"profile_{tag}")
 dst = os.path.join(root, "profiles")
@@ -51,7 +56,8 @@ def per_dispatch(counter, kernel_substr):
 
 # HBM bytes per launch of the kernel that dominates the profiled run (k_trace: persistent pipeline,
 # k_extend: wavefront pipeline); bench.py reads the file of the kernel it ran for roofline.traffic
-for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_traffic.json")):
+for kernel in ("k_extend", "k_trace"):
+    fname = f"{round_tag}_traffic_{key}.json"
     fetch, nf = per_dispatch("FETCH_SIZE", kernel)
     write, nw = per_dispatch("WRITE_SIZE", kernel)
     if fetch is None or write is None:
@@ -75,10 +81,13 @@ for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_tr
             v, _ = per_dispatch(counter, kernel)
             if v is not None:
                 busy[name] = v * scale / cyc
+    if pipe is not None and (kernel == "k_extend") != (pipe == 0):
+        continue  # not the kernel whose launches the run timed
     traffic = {
         "kernel": kernel,
+        "workload": key,
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
-                   + (f" --pipeline {pipe}" if pipe is not None else ""),
+                   + " --no-secondary [workload arguments]",
         "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write, "launches": nf,
         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
         "segments_per_launch": segs,
@@ -88,4 +97,5 @@ for kernel, fname in (("k_trace", "trace_traffic.json"), ("k_extend", "extend_tr
     }
     json.dump(traffic, open(os.path.join(dst, fname), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
+    break
 print(buf.getvalue()[:3000])
