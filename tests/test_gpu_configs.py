@@ -179,3 +179,50 @@ def test_the_nan_sample_of_the_reference_s_roulette_is_reproduced(device, outsid
         assert np.isnan(img[634, 833, :3]).all() and img[634, 833, 3] == 1.0, pipeline
         assert np.array_equal(img[576:704, 768:896], ref[576:704, 768:896], equal_nan=True), pipeline
         assert (~np.isfinite(img[..., :3]).all(axis=2)).sum() == 1, pipeline
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0))
+
+
+def test_c2_full_resolution_frames_match_the_oracle(device, cornell, cornell_oracle):
+    """1920x1080, 8 bounces: two whole frames at the benchmark's resolution against the oracle, bit for bit, on every
+    organisation (the oracle takes a fraction of a second per frame on the box's host cores)."""
+    w, h, bounces = 1920, 1080, 8
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, 2, seed=0x5EED)
+    ref, st = O.render_frames(cornell_oracle, ubos, w, h, bounces)
+    assert st["paths"] == 2 * w * h
+    device.upload_scene(cornell)
+    for pipeline in ALL_PIPELINES:
+        img, gst = _render(device, cornell, ubos, w, h, bounces, pipeline, upload=False)
+        assert gst.paths == st["paths"] and gst.segments == st["segments"], pipeline
+        assert rel_l2(img, ref) <= 1e-4
+        assert np.array_equal(img, ref), pipeline
+
+
+def test_c3_full_resolution_frame_matches_the_oracle(device, outside):
+    s, osc = outside
+    w, h, bounces = 1920, 1080, 8
+    ubos = L.frame_ubos(s.camera_world, s.fov_y, 1, seed=0x5EED)
+    ref, st = O.render_frames(osc, ubos, w, h, bounces)
+    device.upload_scene(s)
+    for pipeline in (L.PIPELINE_WAVEFRONT, L.PIPELINE_HYBRID):
+        img, gst = _render(device, s, ubos, w, h, bounces, pipeline, upload=False)
+        assert gst.paths == w * h and gst.segments == st["segments"], pipeline
+        assert _same_bits(img, ref), pipeline
+
+
+def test_c4_and_c5_full_resolution_frames_match_the_oracle(device, cornell, cornell_oracle, outside):
+    """3840x2160: one whole frame of the Cornell box at 8 bounces and of the open scene at 16 bounces against the
+    oracle, bit for bit (the organisation the library chooses by itself, and the persistent one)."""
+    w, h = 3840, 2160
+    s, osc = outside
+    for scene, oscene, bounces in ((cornell, cornell_oracle, 8), (s, osc, 16)):
+        ubos = L.frame_ubos(scene.camera_world, scene.fov_y, 1, seed=0x5EED)
+        ref, st = O.render_frames(oscene, ubos, w, h, bounces)
+        device.upload_scene(scene)
+        for pipeline in (L.PIPELINE_AUTO, L.PIPELINE_PERSISTENT):
+            img, gst = _render(device, scene, ubos, w, h, bounces, pipeline, upload=False)
+            assert gst.paths == w * h and gst.segments == st["segments"], (bounces, pipeline)
+            assert _same_bits(img, ref), (bounces, pipeline)
+    device.upload_scene(cornell)
