@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence in one GPU call: kernel-trace statistics and PMC passes of the default workload and of the open
+# Evidence in one GPU call: kernel-trace statistics and PMC passes of the default workload and of the open
 # scene, the weak/strong scaling prediction from per-rank shares, and a bench line with the secondary runs.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r3b

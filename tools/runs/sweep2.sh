@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds variants of liblpt_hip.so (extra -D flags) on the CPU here, then in ONE GPU call benches each on the Cornell
-# box and on the open scene (wavefront organisation).   tools/r3/sweep2.sh name1:"-DX=1" name2:"..." ...
+# box and on the open scene (wavefront organisation).   tools/runs/sweep2.sh name1:"-DX=1" name2:"..." ...
 set -e
 cd "$(dirname "$0")/../.."
 V=logipathtracer_amd/lib/variants

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Batch-size and hand-over sweep of the default workload: steps of 32/64/128 frames, the wavefront organisation handing over
+# to its persistent launch at bounce 3..7 or never, and one run each of the open scene and of the 4K resolution.
 mkdir -p gpurun_out/r3a
 for t in 0 3 4 5 6 7; do
   echo "== tail $t"
