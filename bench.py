@@ -385,7 +385,10 @@ def main():
     # LPT_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then
     # share devices and the gather goes through host memory); the real run uses RCCL ("nccl").
     backend = os.environ.get("LPT_BENCH_BACKEND", "nccl")
-    device_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    # (a launcher that shows every rank only its own GPU leaves one visible device per process: index 0 then; whether
+    # the ranks really sit on different GPUs is checked below by PCI address)
+    n_visible = max(1, torch.cuda.device_count())
+    device_index = local_rank % n_visible if (backend == "gloo" or local_rank >= n_visible) else local_rank
     torch.cuda.set_device(device_index)
     cuda_dev = torch.device("cuda", device_index)
     if world > 1:

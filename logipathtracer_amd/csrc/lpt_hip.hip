@@ -1450,11 +1450,19 @@ int lpt_create(int device, lpt_ctx** out) {
   // this GPU's copy of the static scratch array (the device is current here)
   if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&c->dStatic), HIP_SYMBOL(scratch))) != hipSuccess)
     return bail("hipGetSymbolAddress(scratch)", e);
-  if (device < kMaxStaticDevices) {  // the event that orders this GPU's users of the array
-    std::lock_guard<std::mutex> lock(g_staticMutex);
-    if (!g_staticUse[device].done &&
-        (e = hipEventCreateWithFlags(&g_staticUse[device].done, hipEventDisableTiming)) != hipSuccess)
-      return bail("hipEventCreate", e);
+  if (device < kMaxStaticDevices) {  // the event that orders this GPU's users of the array (created once per GPU)
+    bool have;
+    {
+      std::lock_guard<std::mutex> lock(g_staticMutex);
+      have = g_staticUse[device].done != nullptr;
+    }
+    if (!have) {
+      hipEvent_t ev = nullptr;
+      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+      std::lock_guard<std::mutex> lock(g_staticMutex);
+      if (!g_staticUse[device].done) g_staticUse[device].done = ev;
+      else (void)hipEventDestroy(ev);  // another thread's lpt_create was first
+    }
   }
   void* flags = nullptr;
   if ((e = hipHostMalloc(&flags, (4 + kReportWords) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
