@@ -43,6 +43,12 @@ assert np.all(got[..., 3] == 2.0)
 t = torch.tensor([1.5, float(dev.stats().segments)], dtype=torch.float64, device="cuda:0")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert float(t[0]) == 1.5
+# the per-rank reports travel through all_gather_object on the same group
+from logipathtracer_amd import ranks as R
+st = dev.stats()
+reports = R.collect(R.rank_report(0, 0, 0, {"device_ms": st.device_ms, "segments": st.segments, "paths": st.paths, "elapsed": 0.1},
+                                  dev.owned_slots()))
+assert len(reports) == 1 and reports[0]["device"]["pci"] and reports[0]["device"]["uuid"] and R.shared_devices(reports) == []
 dist.barrier()
 dist.destroy_process_group()
 dev.close()
