@@ -84,11 +84,16 @@ void* lpth_scene_load(const char* gltf_path, int builder, lpt_ctx* ctx) {
     handle->scene = scenes.at(0);
     handle->converter = std::make_unique<PTSceneConverter>(ctx);
     handle->converter->setMeshBuilder((PTSceneConverter::MeshBuilder)builder);
-    if (const char* e = std::getenv("LPT_BVH_CHILD_ORDER")) {
+    {  // builder parameters for comparison runs (defaults otherwise)
       lsg::bvh::BuildOptions o;
-      o.childOrder = std::atoi(e);
-      if (const char* l = std::getenv("LPT_BVH_LEAF")) o.maxLeafSize = (uint32_t)std::atoi(l);
-      handle->converter->setBuildOptions(o);
+      bool any = false;
+      if (const char* e = std::getenv("LPT_BVH_CHILD_ORDER")) { o.childOrder = std::atoi(e); any = true; }
+      if (const char* e = std::getenv("LPT_BVH_LEAF")) { o.maxLeafSize = o.minLeafSize = (uint32_t)std::atoi(e); any = true; }
+      if (const char* e = std::getenv("LPT_BVH_MIN_LEAF")) { o.minLeafSize = (uint32_t)std::atoi(e); any = true; }
+      if (const char* e = std::getenv("LPT_BVH_TRAVERSAL_COST")) { o.traversalCost = (float)std::atof(e); any = true; }
+      if (const char* e = std::getenv("LPT_BVH_BINS")) { o.bins = (uint32_t)std::atoi(e); any = true; }
+      if (const char* e = std::getenv("LPT_BVH_SPLIT_ALPHA")) { o.splitAlpha = (float)std::atof(e); any = true; }
+      if (any) handle->converter->setBuildOptions(o);
     }
     handle->converter->loadScene(handle->scene);
     h = handle.release();

