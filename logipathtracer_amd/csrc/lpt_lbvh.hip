@@ -8,7 +8,8 @@
 //   mutual choices merge, the cluster list is compacted, until one cluster is left.  The tree follows the
 //   geometry (surface area of the merged boxes) instead of the bits of the codes: SAH-class quality.
 // The tree is then written out on the host in depth-first order as interchange nodes (include/lpt.h:
-// lpt_bvh_node), with subtrees of at most kLeafSize triangles collapsed into leaves.  Stands in for
+// lpt_bvh_node); subtrees of at most kLeafSize triangles become leaves where the surface-area heuristic finds that
+// cheaper than descending into them.  Stands in for
 // lsg::bvh::SplitBVHBuilder at src/PTSceneConverter.cpp:97-101 of the reference.
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -28,6 +29,7 @@ namespace {
 #define LPT_GPU_BVH_LEAF 4
 #endif
 constexpr uint32_t kLeafSize = LPT_GPU_BVH_LEAF;
+constexpr float kTraversalCost = 1.5f;  // an inner-node visit in units of one triangle test
 
 #define LB_HIP(ctx, call)                                                                      \
   do {                                                                                         \
@@ -475,6 +477,7 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
   // Triangles under every internal node (children before parents: iterative post-order); also rejects
   // anything that is not a tree over all n leaves.
   std::vector<uint32_t> tris(nInternal, 0u);
+  std::vector<uint8_t> asLeaf;
   {
     std::vector<uint32_t> order;
     order.reserve(nInternal);
@@ -493,6 +496,33 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
     for (size_t k = order.size(); k-- > 0;) {
       const uint32_t i = order[k];
       tris[i] = (left[i] < nInternal ? tris[left[i]] : 1u) + (right[i] < nInternal ? tris[right[i]] : 1u);
+    }
+    // Which subtrees become leaves: of those with at most kLeafSize triangles, the ones that are cheaper to test
+    // whole than to descend into (surface-area heuristic, costs in units of one triangle test, an inner-node visit
+    // at kTraversalCost: the rule of the host builder).  cost[] = cheapest way to handle the subtree.
+    auto area = [&](uint32_t node) {
+      const float* mn = &nodeMin[3 * (size_t)node];
+      const float* mx = &nodeMax[3 * (size_t)node];
+      const float d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+      if (!(d[0] >= 0.0f && d[1] >= 0.0f && d[2] >= 0.0f)) return 0.0f;
+      return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+    };
+    std::vector<float> cost(nInternal, 0.0f);
+    asLeaf.assign(nInternal, 0);
+    for (size_t k = order.size(); k-- > 0;) {
+      const uint32_t i = order[k];
+      const uint32_t l = left[i], r = right[i];
+      const float a = area(i);
+      const float cl = l < nInternal ? cost[l] : 1.0f, cr = r < nInternal ? cost[r] : 1.0f;
+      // a box without extent (or a non-finite one) gives no ratio: keep its triangles together
+      const float split = a > 0.0f && a < INFINITY ? kTraversalCost + (area(l) * cl + area(r) * cr) / a : INFINITY;
+      const float whole = (float)tris[i];
+      if (tris[i] <= kLeafSize && !(split < whole)) {
+        asLeaf[i] = 1;
+        cost[i] = whole;
+      } else {
+        cost[i] = split < INFINITY ? split : whole;
+      }
     }
     if ((rootId < nInternal ? tris[rootId] : 1u) != n)
       return lpt_internal_fail(ctx, LPT_ERR_INVALID, "GPU BVH build produced a malformed tree");
@@ -514,7 +544,7 @@ extern "C" int lpt_build_mesh_bvh(lpt_ctx* ctx, int builder, const float* positi
     std::memset(&g, 0, sizeof g);
     put_box(g, &nodeMin[3 * (size_t)it.node], &nodeMax[3 * (size_t)it.node]);
     if (it.parentSlot != 0xFFFFFFFFu) nodesOut[it.parentSlot].indices[it.side] = slot;
-    if (it.node >= nInternal || tris[it.node] <= kLeafSize) {
+    if (it.node >= nInternal || asLeaf[it.node]) {
       g.isLeaf = 1u;
       g.indices[0] = placed;
       gather.assign(1, it.node);
