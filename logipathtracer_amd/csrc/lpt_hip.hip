@@ -117,15 +117,18 @@ __attribute__((amdgpu_waves_per_eu(LPT_EXTEND_WAVES_PER_SIMD, LPT_EXTEND_WAVES_P
 __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
                                                    const float4* __restrict__ qd, QueueFill fill,
                                                    float4* __restrict__ hits, uint32_t* cursor) {
-// The 24 hottest nodes (the top of the object tree) in LDS: what fits beside the stacks without costing
-// a resident workgroup.  Measured: -2 % kernel time on the Cornell box, -6 % on a 70-object scene; 32 and
-// more cost occupancy and lose (85: +3 %, 150: +10 %, 300: +25 %).
+// The hottest nodes (the top of the object tree and of the largest meshes) in LDS: as many as fit beside the stacks
+// without costing a resident workgroup — seven workgroups share the CU's 160 KiB, so 80 nodes with the 16-entry
+// stacks, 24 with deeper ones.  Measured: 24 nodes -2 % kernel time on the Cornell box, -6 % on a 70-object scene;
+// 80 instead of 24 with 16-entry stacks another -1 %; sizes that cost occupancy lose (20-entry stacks: 48 to 80
+// nodes +2 %; earlier, 150: +10 %, 300: +25 %).
 #ifndef LPT_EXTEND_CACHE_NODES
-#define LPT_EXTEND_CACHE_NODES 24
+#define LPT_EXTEND_CACHE_NODES (S <= 16 ? 80 : 24)
 #endif
+  constexpr int kCacheNodes = LPT_EXTEND_CACHE_NODES;
   __shared__ uint32_t stack[S * kBlock];
-  __shared__ __attribute__((aligned(16))) float cache[LPT_EXTEND_CACHE_NODES > 0 ? LPT_EXTEND_CACHE_NODES * kCacheStride : 4];
-  extend_persistent<S, kBlock, LPT_EXTEND_CACHE_NODES>(sc, qo, qd, fill, hits, cursor, stack, cache);
+  __shared__ __attribute__((aligned(16))) float cache[kCacheNodes > 0 ? kCacheNodes * kCacheStride : 4];
+  extend_persistent<S, kBlock, kCacheNodes>(sc, qo, qd, fill, hits, cursor, stack, cache);
 }
 
 // Camera rays of a batch: generated, queued for the shading kernel and traced, 64 consecutive path ids
