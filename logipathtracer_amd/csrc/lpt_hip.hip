@@ -110,20 +110,26 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
 
 // Closest hit for every queued ray: persistent waves, node stacks in LDS, rays handed out
 // through `cursor` (one set of cursors, kCursorWords words zeroed before the launch).  See lpt_extend.h.
-template <int S>
-#ifdef LPT_EXTEND_WAVES_PER_SIMD  // comparison builds: resident waves per SIMD forced (default: what registers and LDS allow, 7)
-__attribute__((amdgpu_waves_per_eu(LPT_EXTEND_WAVES_PER_SIMD, LPT_EXTEND_WAVES_PER_SIMD)))
+// Resident waves per SIMD: eight with the 16-entry stacks (64 registers, no spill; eight workgroups' stacks and 48
+// cached nodes fill the LDS exactly), otherwise what registers and LDS allow (seven with 20-entry stacks, fewer with
+// deeper ones).  Measured on the Cornell box with 16-entry stacks: 8 waves and 48 cached nodes 35.90 ms per step, 8 waves
+// and 24 nodes 36.24, 7 waves and 80 nodes 36.73.  LPT_EXTEND_WAVES_PER_SIMD forces one value for comparison builds.
+#ifdef LPT_EXTEND_WAVES_PER_SIMD
+#define LPT_EXTEND_MIN_WAVES(S) LPT_EXTEND_WAVES_PER_SIMD
+#else
+#define LPT_EXTEND_MIN_WAVES(S) ((S) <= 16 ? 8 : 1)
 #endif
+template <int S>
+__attribute__((amdgpu_waves_per_eu(LPT_EXTEND_MIN_WAVES(S), 8)))
 __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
                                                    const float4* __restrict__ qd, QueueFill fill,
                                                    float4* __restrict__ hits, uint32_t* cursor) {
 // The hottest nodes (the top of the object tree and of the largest meshes) in LDS: as many as fit beside the stacks
-// without costing a resident workgroup — seven workgroups share the CU's 160 KiB, so 80 nodes with the 16-entry
-// stacks, 24 with deeper ones.  Measured: 24 nodes -2 % kernel time on the Cornell box, -6 % on a 70-object scene;
-// 80 instead of 24 with 16-entry stacks another -1 %; sizes that cost occupancy lose (20-entry stacks: 48 to 80
-// nodes +2 %; earlier, 150: +10 %, 300: +25 %).
+// without costing a resident workgroup — 48 beside eight workgroups' 16-entry stacks, 24 beside seven workgroups'
+// 20-entry stacks.  Measured: 24 nodes -2 % kernel time on the Cornell box, -6 % on a 70-object scene; sizes that cost
+// occupancy lose (20-entry stacks: 48 to 80 nodes +2 %; earlier, 150: +10 %, 300: +25 %).
 #ifndef LPT_EXTEND_CACHE_NODES
-#define LPT_EXTEND_CACHE_NODES (S <= 16 ? 80 : 24)
+#define LPT_EXTEND_CACHE_NODES (S <= 16 ? 48 : 24)
 #endif
   constexpr int kCacheNodes = LPT_EXTEND_CACHE_NODES;
   __shared__ uint32_t stack[S * kBlock];
