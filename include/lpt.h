@@ -94,7 +94,7 @@ typedef enum lpt_status {
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
 /* Kernel organisation; all produce identical pixels.
- * AUTO (default): HYBRID; WAVEFRONT for batches of 24 Mi paths and more; PERSISTENT when
+ * AUTO (default): HYBRID; WAVEFRONT for batches of 18 Mi paths and more; PERSISTENT when
  *            the ray queues do not fit in device memory.
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (128 bytes of
  *            queues per path in flight); the first segment runs in the packet kernel, and from the

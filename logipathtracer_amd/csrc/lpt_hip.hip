@@ -1860,11 +1860,12 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     //  - WAVEFRONT (one extend and one shade launch per bounce while the queues are long, the rest in one
     //    persistent launch) keeps seven waves per SIMD in the search and full waves in shading: ahead once a
     //    batch amortises its launches.  Cornell box 1080p, G segments/s by frames per batch (wavefront / hybrid):
-    //    4: 5.85 / 6.34, 8: 7.06 / 7.22, 16: 8.09 / 7.65, 32: 8.73 / 7.90, 64: 9.10 / 8.02, 128: 9.29 / 8.08;
+    //    2: 4.36 / 4.84, 4: 6.03 / 6.64, 6: 6.95 / 7.22, 8: 7.45 / 7.50, 10: 7.84 / 7.69, 12: 8.18 / 7.86, 16: 8.58 / 8.06,
+    //    24: 9.09 / 8.25: they cross at nine frames, 18 Mi paths;
     //  - PERSISTENT (no queues, 16 instead of 64 / 128 bytes per path in flight) when the queues do not fit.
     c->activePipeline = c->pipeline;
     if (c->pipeline == LPT_PIPELINE_AUTO) {
-      const bool largeBatch = (double)fif * c->part.nSlots >= 24.0 * 1024 * 1024;
+      const bool largeBatch = (double)fif * c->part.nSlots >= 18.0 * 1024 * 1024;
       c->activePipeline = largeBatch ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_HYBRID;
     }
     rc = ensure_pool(c, fif);
