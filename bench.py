@@ -167,7 +167,7 @@ def traffic_profile(key, kernel, pipeline):
     return t, "profiles/" + os.path.basename(best[1])
 
 
-def roofline(wl, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext_launches, n_cus, timed_bounces):
+def roofline(wl, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext_launches, n_cus, timed_bounces, stack=None):
     """Roofline block of the dominant kernel: k_extend (wavefront organisation) or k_trace.
 
     Top level, as the measurement contract defines it: bound = HBM, achieved = algorithmic bytes per traced
@@ -249,13 +249,13 @@ def roofline(wl, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext_l
         except Exception:
             pass
     return {
-        "kernel": kernel, "bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": kernel + (f"<{stack['entries_per_lane']}>" if stack else ""), "bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": algorithmic_gbs / HBM_PEAK_GBS, "traffic": traffic,
         "cache_resident": bool(algorithmic_gbs > HBM_PEAK_GBS or (hbm["measured_gbs"] or algorithmic_gbs) < 0.5 * algorithmic_gbs),
         "note": f"achieved = algorithmic bytes of the segments {kernel} traced (bounces {lo} to {hi - 1}) / its time (HIP events "
                 "around every launch on the context's stream); traffic = HBM bytes per launch by the PMC digest named in "
                 "hbm.source.  The kernel is bound by the L1 gather path and vector issue, not by HBM: see l1_gather",
-        "timed_bounces": [lo, hi],
+        "timed_bounces": [lo, hi], "traversal_stack": stack,
         "avg_launch_ms": ext_ms / launches, "launches": ext_launches, "segments_per_launch": kernel_seg / launches,
         "inner_nodes_per_segment": n_inner, "nodes_fetched_per_segment": n_node, "tris_per_segment": n_tri,
         "objects_entered_per_segment": n_obj, "hits_per_segment": p_hit,
@@ -281,6 +281,7 @@ def measure(dev, ubos, spp_step, steps, warmup, barrier):
         out["extend_launches"] += st.extend_launches
         out["device_ms"] += st.device_ms
         out["pipeline"] = st.pipeline
+        out["stack"] = {"need": int(st.stack_need), "entries_per_lane": int(st.stack_entries)}
         ranges.append((int(st.timed_bounce_lo), int(st.timed_bounce_hi)))
     barrier()
     out["elapsed"] = time.perf_counter() - t0
@@ -347,7 +348,7 @@ def run_secondary(L, device_index, n_cus, spec):
     roof = None
     if m["extend_ms"] > 0:
         roof = roofline(wl, scene, ubos, counters, m["pipeline"], m["kernel_segments"], m["extend_ms"], m["extend_launches"],
-                        n_cus, m["timed_bounces"])
+                        n_cus, m["timed_bounces"], m.get("stack"))
     return {
         "config": spec["config"], "workload": describe(wl, spp, spp), "value": m["segments"] / m["elapsed"] / 1e6,
         "unit": "Msamples/s", "steps": steps, "warmup": warmup, "ms_per_step": m["elapsed"] * 1e3 / steps,
@@ -509,7 +510,7 @@ def main():
         result["kernel_segments"] = float(m["kernel_segments"])  # segments traced by the launches extend_ms times
         n_cus = torch.cuda.get_device_properties(device_index).multi_processor_count
         result["roofline"] = roofline(wl, scene, ubos, counters, used_pipeline, m["kernel_segments"], m["extend_ms"],
-                                      m["extend_launches"], n_cus, m["timed_bounces"]) if m["extend_ms"] > 0 else None
+                                      m["extend_launches"], n_cus, m["timed_bounces"], m.get("stack")) if m["extend_ms"] > 0 else None
         if world == 1 and not args.no_secondary:
             dev.close()  # its queues (tens of GB) are not needed any more
             result["secondary"] = [run_secondary(L, device_index, n_cus, spec) for spec in SECONDARY]

@@ -133,6 +133,8 @@ typedef struct lpt_stats {
   uint64_t kernel_segments; /* the segments traced by the launches that extend_ms times */
   uint32_t timed_bounce_lo; /* those launches traced the segments of bounces [lo, hi) (of the call's last batch; */
   uint32_t timed_bounce_hi; /*  the wavefront organisation chooses per batch where its persistent launch takes over) */
+  uint32_t stack_need;      /* traversal-stack entries the uploaded scene can need at once (computed at upload) */
+  uint32_t stack_entries;   /* entries per lane of the kernel variant that serves it: 16, 20, 24, 32, 48 or 64 */
 } lpt_stats;
 
 /* ---- context ---------------------------------------------------------------- */

@@ -61,7 +61,8 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("frames", C.c_uint64),
                 ("device_ms", C.c_double), ("extend_ms", C.c_double),
                 ("extend_launches", C.c_uint32), ("pipeline", C.c_uint32), ("kernel_segments", C.c_uint64),
-                ("timed_bounce_lo", C.c_uint32), ("timed_bounce_hi", C.c_uint32)]
+                ("timed_bounce_lo", C.c_uint32), ("timed_bounce_hi", C.c_uint32),
+                ("stack_need", C.c_uint32), ("stack_entries", C.c_uint32)]
 
 
 # every symbol include/lpt.h declares

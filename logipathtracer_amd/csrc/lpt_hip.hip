@@ -2012,6 +2012,9 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   out->pipeline = (uint32_t)c->activePipeline;
   out->timed_bounce_lo = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? 0u : c->timedLo;
   out->timed_bounce_hi = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? (uint32_t)c->maxBounces : c->timedHi;
+  out->stack_need = (uint32_t)c->stackNeed;
+  out->stack_entries = c->stackNeed <= 16 ? 16u : c->stackNeed <= 20 ? 20u : c->stackNeed <= 24 ? 24u : c->stackNeed <= 32 ? 32u
+                       : c->stackNeed <= 48 ? 48u : 64u;
   return LPT_OK;
 }
 
