@@ -402,6 +402,14 @@ struct Surface {
   bool outside;       // ray arrives on the side the unflipped normal points to (:304)
 };
 
+// The tangent frame about the shading normal (path_tracing.comp:274-275, and again :280-281 after a normal map):
+// a function of the normal alone, so a kernel that sets a hit aside may keep the normal and rebuild the frame.
+__device__ __forceinline__ void shading_frame(f3 ff, f3& u, f3& v) {
+  const f3 axis = (__builtin_fabsf(ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
+  u = normalize3(cross3(axis, ff));
+  v = cross3(ff, u);
+}
+
 // :219-304.  Returns false on a miss; `sample` then holds the path's radiance.
 __device__ __forceinline__ bool shade_begin(const DScene& sc, Path& p, const Hit& hit, Surface& sf, f3& sample) {
   if (hit.t == kInfinity) {  // :220-223 — assignment: radiance gathered so far is dropped
@@ -462,16 +470,12 @@ __device__ __forceinline__ bool shade_begin(const DScene& sc, Path& p, const Hit
   f3 nsum = (f3{n0.x, n0.y, n0.z} * bary.x + f3{n1.x, n1.y, n1.z} * bary.y) + f3{n2.x, n2.y, n2.z} * bary.z;
   f3 normal = normalize3(xform_mat3(nrm, nsum));  // :272 (mat3(worldMatrix), not inverse-transpose)
   sf.ff = (dot3(normal, p.d) < 0.0f) ? normal : normal * -1.0f;
-  f3 axis = (__builtin_fabsf(sf.ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
-  sf.u = normalize3(cross3(axis, sf.ff));
-  sf.v = cross3(sf.ff, sf.u);
+  shading_frame(sf.ff, sf.u, sf.v);
   if (textured && texNormal != kNoTexture16) {  // :277-282
     const f4 c = sample_texture(sc.textures, texNormal, uvx, uvy);
     const f3 tn = normalize3(f3{c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f});
     sf.ff = normalize3((sf.u * tn.x + sf.v * tn.y) + sf.ff * tn.z);
-    axis = (__builtin_fabsf(sf.ff.x) > 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
-    sf.u = normalize3(cross3(axis, sf.ff));
-    sf.v = cross3(sf.ff, sf.u);
+    shading_frame(sf.ff, sf.u, sf.v);
   }
   f3 nd = -p.d;
   sf.viewDir = f3{dot3(nd, sf.u), dot3(nd, sf.v), dot3(nd, sf.ff)};

@@ -148,24 +148,221 @@ __global__ __launch_bounds__(kBlock) void k_primary(const TNode* __restrict__ no
   Hit hit;
   bool valid;
   uint32_t pid;
-  primary_packet<true>(nodes, tris, otrav, rootRef, P, ubos, nFrames, validBefore, nValid, q, hits, p, hit, valid, pid);
+  primary_packet<true>(nodes, tris, otrav, rootRef, P, ubos, nFrames, validBefore, nValid, q, hits,
+                       blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), p, hit, valid, pid);
 }
 
-// ---- Heitz walks of a whole workgroup ---------------------------------------------------
-// The random walks of a block's hits differ widely in length on rough materials (1 to 16 orders), and
-// within an order most of the work (the scattering event) is only done by the walks that have not just
-// left the microsurface: a loop per lane leaves most of a wave idle.  Here every lane takes the start of
-// its own walk — height, scattering, height: where most walks on smooth materials end — and walks still
-// going are parked in LDS as jobs.  A job is a walk that is about to scatter; the lowest threads of the
-// block take the jobs up, LPT_WALK_PASS_STEPS times (scatter, next height) per pass, and the list of
-// unfinished jobs is compacted between passes: the waves that work are full and their lanes in step.
-// A job carries everything a step needs; the operations and random numbers of a walk are those of
-// heitz_bsdf_unified in the same order.
-#ifndef LPT_WALK_PASS_STEPS
-#define LPT_WALK_PASS_STEPS 2
-#endif
-constexpr int kWalkJobWords = 16;  // lightDir 0-2, energy 3-5, height 6, order|outside|kind 7, rng 8-9, F0 10-12, alpha, iorOut, iorIn
+// Bookkeeping of a shaded queue entry: the radiance this bounce emitted joins what the path has gathered
+// in samples[path id]; a path that ends without ever having gathered anything leaves zero there.
+__device__ __forceinline__ void settle_emitted(float4* __restrict__ samples, const Path& p, uint32_t& pidWord) {
+  if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
+    // gathered + mask*emission, path_tracing.comp:269 (adding a zero product would change nothing)
+    const uint32_t slot = pidWord & ~kAccStored;
+    f3 acc = p.acc;
+    if (pidWord & kAccStored) {
+      const float4 g = samples[slot];
+      acc = f3{g.x, g.y, g.z} + p.acc;
+    }
+    samples[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    pidWord |= kAccStored;
+  }
+}
+__device__ __forceinline__ void settle_ended(float4* __restrict__ samples, uint32_t pidWord) {
+  if (!(pidWord & kAccStored)) samples[pidWord & ~kAccStored] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // it never gathered anything
+}
+__device__ __forceinline__ void settle_entry(float4* __restrict__ samples, const Path& p, uint32_t& pidWord, bool alive) {
+  settle_emitted(samples, p, pidWord);
+  if (!alive) settle_ended(samples, pidWord);
+}
 
+// ---- Heitz walks of a workgroup: the pool ---------------------------------------------------
+// The random walks of a group of hits differ widely in length on rough materials (1 to 16 orders), and within
+// an order most of the work (the scattering event) is only done by the walks that have not just left the
+// microsurface: a loop per lane leaves most of a wave idle, and finishing the walks group by group keeps whole
+// waves busy for the last handful (on rough materials that took two thirds of the shading kernel's time).
+// Here every lane takes the start of its own walk — height, scattering, height: where most walks on smooth
+// materials end.  A walk that is then about to scatter again is set aside: its state goes to a pool in LDS,
+// what the rest of the bounce needs from the hit (position, normal, throughput, path id) goes to a queue entry
+// that belongs to the path (`cont`), and the thread moves on to the next group of hits.  Whenever kPoolRun walks
+// wait, the workgroup advances whole waves of them by LPT_WALK_PASS_STEPS orders; a walk that ends finishes its
+// path there.  The pool is a stack: a pass takes the walks on top and puts back those that go on.  What is left
+// when the workgroup runs out of hits is run to the end.  The operations and random numbers of a walk are those
+// of heitz_bsdf_unified in the same order, and every path owns its random-number state, so the order in which
+// walks are advanced changes no result.
+// Measured (1080p, 8 bounces, 64 frames per batch) against finishing the walks group by group: rough 400 k-triangle
+// terrain scene, shading kernel 9.4 -> 5.7 ms per launch; Cornell box unchanged.  Steps per pass 1 / 2 / 3:
+// +1 % / 0 / -0.5 %; kPoolRun 64 ... 256: within 0.5 %; no inline start (every walk through the pool): -12 % on the
+// Cornell box; two scattering events inline: -1 % on the terrain.
+#ifndef LPT_WALK_PASS_STEPS
+#define LPT_WALK_PASS_STEPS 1
+#endif
+#ifndef LPT_WALK_HEAD_ORDERS  // scattering events a lane runs inline before its walk goes to the pool
+#define LPT_WALK_HEAD_ORDERS 1
+#endif
+#ifndef LPT_WALK_POOL_RUN
+#define LPT_WALK_POOL_RUN 128
+#endif
+constexpr uint32_t kPoolRun = LPT_WALK_POOL_RUN;
+static_assert(kPoolRun >= 64u && kPoolRun <= (uint32_t)kBlock && kPoolRun % 64u == 0u, "passes take whole waves");
+constexpr uint32_t kPoolSlots = kPoolRun + kBlock;  // fewer than kPoolRun wait when a group of kBlock hits is shaded
+// words of a pooled walk: lightDir 0-2, energy 3-5, height 6, order | walk side << 8 | lobe << 9 | ray side << 12 in 7,
+// rng 8-9, F0 10-12, alpha 13, ior 14, index of the path's entry in `cont` 15
+constexpr int kWalkJobWords = 16;
+constexpr uint32_t kPoolSurfaceOutside = 0x1000u;
+
+struct WalkPool {
+  float job[kWalkJobWords][kPoolSlots];  // field-major: lanes of a wave touch consecutive words
+  uint32_t waveCount[kBlock / 64];
+};
+
+struct PooledWalk {
+  HeitzWalk w;
+  Rng rng;
+  f3 F0;
+  float alpha, ior;
+  uint32_t kind, entry;
+  bool surfaceOutside;  // the ray arrived on the side the surface normal points to
+};
+
+__device__ __forceinline__ void pool_store(WalkPool& wp, uint32_t j, const PooledWalk& k) {
+  wp.job[0][j] = k.w.lightDir.x;
+  wp.job[1][j] = k.w.lightDir.y;
+  wp.job[2][j] = k.w.lightDir.z;
+  wp.job[3][j] = k.w.energy.x;
+  wp.job[4][j] = k.w.energy.y;
+  wp.job[5][j] = k.w.energy.z;
+  wp.job[6][j] = k.w.height;
+  wp.job[7][j] = as_float((uint32_t)k.w.order | (k.w.outside ? 0x100u : 0u) | (k.kind << 9) |
+                          (k.surfaceOutside ? kPoolSurfaceOutside : 0u));
+  wp.job[8][j] = as_float(k.rng.x);
+  wp.job[9][j] = as_float(k.rng.y);
+  wp.job[10][j] = k.F0.x;
+  wp.job[11][j] = k.F0.y;
+  wp.job[12][j] = k.F0.z;
+  wp.job[13][j] = k.alpha;
+  wp.job[14][j] = k.ior;
+  wp.job[15][j] = as_float(k.entry);
+}
+
+__device__ __forceinline__ void pool_load(const WalkPool& wp, uint32_t j, PooledWalk& k) {
+  k.w.lightDir = f3{wp.job[0][j], wp.job[1][j], wp.job[2][j]};
+  k.w.energy = f3{wp.job[3][j], wp.job[4][j], wp.job[5][j]};
+  k.w.height = wp.job[6][j];
+  const uint32_t packed = as_uint(wp.job[7][j]);
+  k.w.order = (int)(packed & 0xFFu);
+  k.w.outside = (packed & 0x100u) != 0u;
+  k.kind = (packed >> 9) & 7u;
+  k.surfaceOutside = (packed & kPoolSurfaceOutside) != 0u;
+  k.rng = Rng{as_uint(wp.job[8][j]), as_uint(wp.job[9][j])};
+  k.F0 = f3{wp.job[10][j], wp.job[11][j], wp.job[12][j]};
+  k.alpha = wp.job[13][j];
+  k.ior = wp.job[14][j];
+  k.entry = as_uint(wp.job[15][j]);
+}
+
+// Block-wide: the threads with `flag` put `k` on the pool, which holds `count` walks; returns the new count (the
+// same in every thread).  Synchronises the block before (readers of the pool are done) and after.
+__device__ __forceinline__ uint32_t pool_push(WalkPool& wp, uint32_t count, bool flag, const PooledWalk& k) {
+  const unsigned long long b = __ballot(flag);
+  const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+  const uint32_t wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0u) wp.waveCount[wave] = (uint32_t)__popcll(b);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (uint32_t w = 0; w < kBlock / 64; ++w) {
+    const uint32_t n = wp.waveCount[w];
+    if (w < wave) before += n;
+    total += n;
+  }
+  if (flag) pool_store(wp, count + before + below, k);
+  __syncthreads();
+  return count + total;
+}
+
+// The start of a hit's walk, run by the lane that shades the hit.  Returns true if the walk is over (`weight`,
+// `lightDir` hold the sample); otherwise `k` is the walk about to scatter (all of it but `entry`).
+__device__ __forceinline__ bool walk_head(Rng& rng, const Surface& sf, PooledWalk& k, f3& weight, f3& lightDir) {
+  k.kind = sf.interaction;
+  k.F0 = sf.baseLinear;
+  k.alpha = sf.roughness * sf.roughness;
+  k.ior = sf.ior;
+  k.surfaceOutside = sf.outside;
+  const float iorOut = sf.outside ? 1.0f : sf.ior, iorIn = sf.outside ? sf.ior : 1.0f;
+  heitz_walk_begin(k.w, sf.viewDir);
+  bool done = heitz_walk_height(rng, k.w, k.kind, k.alpha);
+  for (int order = 0; order < LPT_WALK_HEAD_ORDERS && !done; ++order) {
+    done = heitz_walk_scatter(rng, k.w, k.kind, k.F0, k.alpha, iorOut, iorIn);
+    if (!done) done = heitz_walk_height(rng, k.w, k.kind, k.alpha);
+  }
+  if (done) weight = heitz_walk_result(k.w, k.kind, k.F0, lightDir);
+  k.rng = rng;
+  return done;
+}
+
+// What a set-aside hit leaves in its queue entry, and how it comes back.
+__device__ __forceinline__ void store_continuation(const Queue& cont, uint32_t entry, const Surface& sf, const Path& p,
+                                                   uint32_t pidWord) {
+  cont.o[entry] = make_float4(sf.posW.x, sf.posW.y, sf.posW.z, as_float(pidWord));
+  cont.d[entry] = make_float4(sf.ff.x, sf.ff.y, sf.ff.z, 0.0f);
+  cont.m[entry] = make_float4(p.mask.x, p.mask.y, p.mask.z, 0.0f);
+}
+
+// Advances the walks on top of the pool — whole waves of them, or with `all` also the wave that is not full — by
+// LPT_WALK_PASS_STEPS orders.  A walk that ends finishes its path (Russian roulette and the rest of
+// path_tracing.comp:306-323) from what store_continuation left in cont[entry].
+// A path that goes on is appended to part queue [lo, ...) of `out` through *countOut, one that ends leaves its
+// radiance settled.  Called by all threads of the block; `pooled` (the same in every thread) is updated.
+template <int STEPS>
+__device__ __forceinline__ void pool_pass(WalkPool& pool, uint32_t& pooled, bool all, const Queue& cont, const Queue& out,
+                                          uint32_t lo, uint32_t* countOut, uint32_t* lds, float4* __restrict__ samples,
+                                          uint32_t bounce, uint32_t maxBounces) {
+  const uint32_t m = min(all ? pooled : (pooled & ~63u), (uint32_t)kBlock), base = pooled - m;
+  bool still = false, alive = false;
+  PooledWalk k;
+  Path p;
+  uint32_t pidWord = 0;
+  if (threadIdx.x < m) {
+    pool_load(pool, base + threadIdx.x, k);
+    const float iorOut = k.surfaceOutside ? 1.0f : k.ior, iorIn = k.surfaceOutside ? k.ior : 1.0f;
+    bool done = false;
+    for (int step = 0; step < STEPS && !done; ++step) {
+      done = heitz_walk_scatter(k.rng, k.w, k.kind, k.F0, k.alpha, iorOut, iorIn);
+      if (!done) done = heitz_walk_height(k.rng, k.w, k.kind, k.alpha);
+    }
+    if (done) {
+      f3 lightDir, sample;
+      const f3 weight = heitz_walk_result(k.w, k.kind, k.F0, lightDir);
+      const float4 o = cont.o[k.entry], d = cont.d[k.entry], t = cont.m[k.entry];
+      Surface sf;
+      sf.posW = f3{o.x, o.y, o.z};
+      sf.ff = f3{d.x, d.y, d.z};
+      shading_frame(sf.ff, sf.u, sf.v);
+      pidWord = as_uint(o.w);
+      p.mask = f3{t.x, t.y, t.z};
+      p.acc = f3{0.0f, 0.0f, 0.0f};  // what this bounce emitted was settled when the walk was set aside
+      p.rng = k.rng;
+      alive = shade_end(p, sf, weight, lightDir, bounce, maxBounces, sample);
+      if (!alive) settle_ended(samples, pidWord);
+    } else {
+      still = true;
+    }
+  }
+  pooled = pool_push(pool, base, still, k);  // its first barrier comes after every load above
+  const uint32_t dst = lo + block_append(alive, countOut, lds);
+  if (alive) store_path(out, dst, p, pidWord);
+}
+
+// ---- Heitz walks of one group of hits, finished before the group's threads go on -------------------
+// For a kernel whose workgroups shade a single group of kBlock hits (k_primary_shade) there is nothing to wait
+// for: every lane takes the start of its own walk, walks still going are parked in LDS as jobs, the lowest
+// threads of the block take the jobs up, LPT_PRIMARY_PASS_STEPS orders per pass, and the list of unfinished jobs is
+// compacted between passes; the lane that owns the hit keeps the rest of its state in registers and picks up the
+// result.  (Measured against setting the hits aside as k_shade does, completed in their entries of the next queue:
+// 23.2 against 23.9 ms per launch on a rough terrain scene, 4.47 against 4.57 on the Cornell box.)
+#ifndef LPT_PRIMARY_PASS_STEPS
+#define LPT_PRIMARY_PASS_STEPS 2
+#endif
 struct WalkShared {
   float job[kWalkJobWords][kBlock];  // field-major: lanes of a wave touch consecutive words
   uint32_t list[2][kBlock];
@@ -252,7 +449,7 @@ __device__ __forceinline__ void walk_block(WalkShared& ws, bool walking, Rng& rn
       const f3 F0{ws.job[10][j], ws.job[11][j], ws.job[12][j]};
       const float ja = ws.job[13][j], jo = ws.job[14][j], ji = ws.job[15][j];
       bool done = false;
-      for (int k = 0; k < LPT_WALK_PASS_STEPS && !done; ++k) {
+      for (int k = 0; k < LPT_PRIMARY_PASS_STEPS && !done; ++k) {
         done = heitz_walk_scatter(jr, jw, kind, F0, ja, jo, ji);
         if (!done) done = heitz_walk_height(jr, jw, kind, ja);
       }
@@ -274,24 +471,6 @@ __device__ __forceinline__ void walk_block(WalkShared& ws, bool walking, Rng& rn
     lightDir = f3{ws.job[0][t], ws.job[1][t], ws.job[2][t]};
     weight = f3{ws.job[3][t], ws.job[4][t], ws.job[5][t]};
     rng = Rng{as_uint(ws.job[8][t]), as_uint(ws.job[9][t])};
-  }
-}
-
-// Bookkeeping of a shaded queue entry: the radiance this bounce emitted joins what the path has gathered
-// in samples[path id]; a path that ends without ever having gathered anything leaves zero there.
-__device__ __forceinline__ void settle_entry(float4* __restrict__ samples, const Path& p, uint32_t& pidWord, bool alive) {
-  const uint32_t slot = pidWord & ~kAccStored;
-  if (p.acc.x != 0.0f || p.acc.y != 0.0f || p.acc.z != 0.0f) {
-    // gathered + mask*emission, path_tracing.comp:269 (adding a zero product would change nothing)
-    f3 acc = p.acc;
-    if (pidWord & kAccStored) {
-      const float4 g = samples[slot];
-      acc = f3{g.x, g.y, g.z} + p.acc;
-    }
-    samples[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-    pidWord |= kAccStored;
-  } else if (!alive && !(pidWord & kAccStored)) {
-    samples[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the path ends without having gathered anything
   }
 }
 
@@ -330,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
   __shared__ uint32_t lds[kBlock / 64 + 1];
   __shared__ uint32_t waveCount[kShadeClasses][kBlock / 64];
   __shared__ uint32_t pending[kShadeClasses][2 * kBlock];  // fewer than kBlock entries each between scans
-  __shared__ WalkShared walk;
+  __shared__ WalkPool pool;
 #if LPT_SHADE_LOBE_TABLE > 0
   // the likely lobe of the first LPT_SHADE_LOBE_TABLE objects, so that the scan below sorts a hit without a
   // dependent gather into the object records
@@ -348,13 +527,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
   uint32_t* countOut = fillOut + part * kCursorStride;
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t nPending[kShadeClasses] = {0u, 0u, 0u};  // same values in every thread of the block
+  uint32_t pooled = 0;                              // Heitz walks waiting in the pool (same in every thread)
 
-  // Shades the first min(count, kBlock) entries of list c (rays that hit something): the hit, the BSDF sample
-  // (the Heitz walks of the block together, see walk_block), Russian roulette; called by all threads.
+  // Shades the first min(count, kBlock) entries of list c (rays that hit something): the hit, the BSDF sample,
+  // Russian roulette; called by all threads.  A Heitz walk that is still going after its first step(s) goes to the
+  // pool, and its path is finished by pool_pass.
   auto shade_list = [&](int c, uint32_t count) {
-    bool began = false, alive = false;
+    bool began = false, alive = false, parked = false;
     Path p;
     Surface sf;
+    PooledWalk k;
     uint32_t pidWord = 0;
     f3 sample{0.0f, 0.0f, 0.0f}, weight{0.0f, 0.0f, 0.0f}, lightDir{0.0f, 0.0f, 0.0f};
     if (threadIdx.x < count) {
@@ -366,15 +548,24 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
       p.acc = f3{0.0f, 0.0f, 0.0f};  // shade_begin leaves this bounce's emitted radiance here (0 + mask*emission)
       p.rng = Rng{as_uint(d.w), as_uint(m.w)};
       pidWord = as_uint(o.w);
+      k.entry = i;
       began = shade_begin(sc, p, Hit{h.x, as_uint(h.y), as_uint(h.z)}, sf, sample);
     }
+    // at the last bounce the sampled direction has no use: every path ends there whatever it is
+    // (path_tracing.comp:306-323 draws from the path's own random numbers, which end with the path)
+    const bool last = bounce + 1u >= maxBounces;
     if (bsdfMode == LPT_BSDF_HEITZ) {
-      walk_block(walk, began, p.rng, sf, weight, lightDir);
-    } else if (began) {
+      if (began && !last && !walk_head(p.rng, sf, k, weight, lightDir)) {
+        parked = true;  // about to scatter again: the rest of this path's bounce waits for the walk
+        settle_emitted(samples, p, pidWord);
+        store_continuation(in, k.entry, sf, p, pidWord);
+      }
+      pooled = pool_push(pool, pooled, parked, k);
+    } else if (began && !last) {
       weight = basic_bsdf(p.rng, sf, lightDir);
     }
-    if (began) {
-      alive = shade_end(p, sf, weight, lightDir, bounce, maxBounces, sample);
+    if (began && !parked) {
+      alive = !last && shade_end(p, sf, weight, lightDir, bounce, maxBounces, sample);
       settle_entry(samples, p, pidWord, alive);
     }
     const uint32_t carry = threadIdx.x + kBlock < count ? pending[c][threadIdx.x + kBlock] : 0u;
@@ -383,8 +574,29 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
     if (threadIdx.x + kBlock < count) pending[c][threadIdx.x] = carry;
   };
 
-  for (uint32_t base = lo + rank * kBlock; base < n; base += blocksOfPart * kBlock) {
+  // One loop with one place each for the three things the workgroup does, most urgent first: advance the pool
+  // when enough walks wait (and, once everything else is done, until it is empty); shade a list that holds a full
+  // group (at the end: what is left of it); look at the next kBlock entries of the part.
+  uint32_t base = lo + rank * kBlock;
+  for (;;) {
+    const bool scanned = base >= n;
+    int c = -1;
+    for (int k = kShadeClasses - 1; k >= 0; --k)
+      if (nPending[k] >= (scanned ? 1u : (uint32_t)kBlock)) c = k;
+    if (pooled >= kPoolRun || (scanned && c < 0 && pooled > 0u)) {
+      pool_pass<LPT_WALK_PASS_STEPS>(pool, pooled, scanned && c < 0 && pooled < 64u, in, out, lo, countOut, lds, samples, bounce, maxBounces);
+      continue;
+    }
+    if (c >= 0) {
+      const uint32_t count = c == 0 ? nPending[0] : (c == 1 ? nPending[1] : nPending[2]);
+      shade_list(c, count);
+      const uint32_t took = min(count, (uint32_t)kBlock);
+      for (int k = 0; k < kShadeClasses; ++k) nPending[k] -= k == c ? took : 0u;
+      continue;
+    }
+    if (scanned) break;
     const uint32_t i = base + threadIdx.x;
+    base += blocksOfPart * kBlock;
     uint32_t cls = kShadeClasses;  // none
     if (i < n) {
       const float4 h = hits[i];
@@ -403,39 +615,34 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, Queue in, const flo
     }
     // ranks within the block, per class
     uint32_t below[kShadeClasses];
-    for (int c = 0; c < kShadeClasses; ++c) {
-      const unsigned long long b = __ballot(cls == (uint32_t)c);
-      below[c] = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-      if ((threadIdx.x & 63u) == 0u) waveCount[c][wave] = (uint32_t)__popcll(b);
+    for (int k = 0; k < kShadeClasses; ++k) {
+      const unsigned long long b = __ballot(cls == (uint32_t)k);
+      below[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      if ((threadIdx.x & 63u) == 0u) waveCount[k][wave] = (uint32_t)__popcll(b);
     }
     __syncthreads();
-    for (int c = 0; c < kShadeClasses; ++c) {
+    for (int k = 0; k < kShadeClasses; ++k) {
       uint32_t before = 0, total = 0;
       for (uint32_t w = 0; w < kBlock / 64; ++w) {
-        const uint32_t k = waveCount[c][w];
-        if (w < wave) before += k;
-        total += k;
+        const uint32_t t = waveCount[k][w];
+        if (w < wave) before += t;
+        total += t;
       }
-      if (cls == (uint32_t)c) pending[c][nPending[c] + before + below[c]] = i;
-      nPending[c] += total;
+      if (cls == (uint32_t)k) pending[k][nPending[k] + before + below[k]] = i;
+      nPending[k] += total;
     }
-    __syncthreads();
-    for (int c = 0; c < kShadeClasses; ++c) {
-      if (nPending[c] >= (uint32_t)kBlock) {
-        shade_list(c, nPending[c]);
-        nPending[c] -= kBlock;
-      }
-    }
-    __syncthreads();  // waveCount and pending are rewritten by the next scan
+    __syncthreads();  // the lists are complete; waveCount may be rewritten by the next scan
   }
-  for (int c = 0; c < kShadeClasses; ++c)
-    if (nPending[c] > 0) shade_list(c, nPending[c]);
 }
 
 // The first segment of every path of a batch in one kernel: camera ray, packet walk (as k_primary) and
 // the shading of what it hit (as k_shade does for bounce 0, without the detour through a ray queue and a
 // hit array).  The pixels of a block mostly hit the same object, so the lanes shade in step without the
 // sorting k_shade does.  Paths that go on are appended to `out`.
+// (Letting a workgroup take several groups of paths in turn, so that Heitz walks can wait across groups as in
+// k_shade, was built and measured: the loop around the packet walk costs registers — 77 spilled at 6 waves per
+// SIMD — and the kernel is mostly the packet walk: -1.7 ms of 23 on a rough terrain scene, +0.2 ms of 4.5 on the
+// Cornell box.  Not kept.)
 // Six waves per SIMD (80 VGPRs): the packet walk is a chain of dependent scalar loads and wants the waves
 // (measured: 4 waves -1.2 %, 5 as the compiler's own choice, 6 +0.7 % Cornell / +1.4 % rough terrain, 8 -0.5 %).
 #ifndef LPT_PRIMARY_WAVES_PER_SIMD
@@ -454,18 +661,20 @@ __global__ __launch_bounds__(kBlock) void k_primary_shade(const TNode* __restric
   bool valid;
   uint32_t pid;
   primary_packet<false>(nodes, tris, otrav, sc.rootRef, P, ubos, nFrames, nullptr, 0u, PrimaryQueue{nullptr, nullptr, nullptr},
-                        nullptr, p, hit, valid, pid);
+                        nullptr, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), p, hit, valid, pid);
+  // with a bounce limit of one every path ends at its first hit whatever direction is sampled there
+  const bool last = maxBounces <= 1u;
   bool alive = false, began = false;
   uint32_t pidWord = pid;
   Surface sf;
   f3 s{0.0f, 0.0f, 0.0f}, weight{0.0f, 0.0f, 0.0f}, lightDir{0.0f, 0.0f, 0.0f};
   if (valid) began = shade_begin(sc, p, hit, sf, s);  // a miss ends the path with s = 0.2 * throughput
   if (bsdfMode == LPT_BSDF_HEITZ) {
-    walk_block(walk, began, p.rng, sf, weight, lightDir);
-  } else if (began) {
+    walk_block(walk, began && !last, p.rng, sf, weight, lightDir);
+  } else if (began && !last) {
     weight = basic_bsdf(p.rng, sf, lightDir);
   }
-  if (began) alive = shade_end(p, sf, weight, lightDir, 0u, maxBounces, s);
+  if (began && !last) alive = shade_end(p, sf, weight, lightDir, 0u, maxBounces, s);
   if (valid) {
     if (hit.t == kInfinity) {
       samples[pid] = make_float4(s.x, s.y, s.z, 0.0f);

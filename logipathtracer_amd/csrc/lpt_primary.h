@@ -59,17 +59,17 @@ struct PrimaryQueue {
 // `valid` says whether the path id is a pixel of the image, `p` is the path at its first segment and `hit`
 // what that segment found.  With STORE the ray is also queued at index f*nValid + validBefore[slot] (or the
 // path id itself when validBefore is null: every slot a pixel) and hits[same index] = (t, obj, prim, 0).
-// Every thread returns (no early exit), so the caller may synchronise the workgroup afterwards.
+// `w` is the number of the wave's packet in the launch (wave-uniform; a number beyond the last pixel block is a packet
+// without pixels).  Every thread returns (no early exit), so the caller may synchronise the workgroup afterwards.
 template <bool STORE>
 __device__ __forceinline__ void primary_packet(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
                                                const ObjTrav* __restrict__ otrav, uint32_t rootRef,
                                                const Partition& P, const lpt_ubo* __restrict__ ubos,
                                                uint32_t nFrames, const uint32_t* __restrict__ validBefore,
                                                uint32_t nValid, const PrimaryQueue& q, float4* __restrict__ hits,
-                                               Path& p, Hit& hit, bool& valid, uint32_t& pid) {
+                                               uint32_t w, Path& p, Hit& hit, bool& valid, uint32_t& pid) {
   const uint32_t lane = threadIdx.x & 63u;
-  // wave w of the launch: pixel block w / nFrames in frame w % nFrames
-  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // packet w of the launch: pixel block w / nFrames in frame w % nFrames
   const uint32_t sb = w / nFrames, fw = w - sb * nFrames;
   valid = sb < (P.nSlots >> 6);
   pid = valid ? fw * P.nSlots + sb * 64u + lane : 0xFFFFFFFFu;
