@@ -520,6 +520,10 @@ __device__ __forceinline__ bool shade_hit(const DScene& sc, Path& p, const Hit& 
                                           uint32_t maxBounces, int bsdfMode, f3& sample) {
   Surface sf;
   if (!shade_begin(sc, p, hit, sf, sample)) return false;
+  if (bounce + 1u >= maxBounces) {  // the path ends here whatever direction is sampled (shade_end's last test)
+    sample = p.acc;
+    return false;
+  }
   f3 lightDir{0.0f, 0.0f, 0.0f};
   f3 weight;
   if (bsdfMode != LPT_BSDF_HEITZ) {

@@ -170,6 +170,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& sc, const Partiti
         const Hit hit{E.x, as_uint(E.y), as_uint(E.z)};
         if (!shade_begin(sc, p, hit, sf, sample)) {
           ended = true;
+        } else if (bounce + 1u >= maxBounces) {  // the path ends here whatever direction is sampled
+          sample = p.acc;
+          ended = true;
         } else if (bsdfMode != LPT_BSDF_HEITZ) {
           weight = basic_bsdf(p.rng, sf, lightDir);
           finish = true;
