@@ -142,13 +142,13 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __re
 __global__ __launch_bounds__(kBlock) void k_primary(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
                                                     const ObjTrav* __restrict__ otrav, uint32_t rootRef, Partition P,
                                                     const lpt_ubo* __restrict__ ubos, uint32_t nFrames,
-                                                    const uint32_t* __restrict__ validBefore, uint32_t nValid,
-                                                    PrimaryQueue q, float4* __restrict__ hits) {
+                                                    uint32_t packetFrames, const uint32_t* __restrict__ validBefore,
+                                                    uint32_t nValid, PrimaryQueue q, float4* __restrict__ hits) {
   Path p;
   Hit hit;
   bool valid;
   uint32_t pid;
-  primary_packet<true>(nodes, tris, otrav, rootRef, P, ubos, nFrames, validBefore, nValid, q, hits,
+  primary_packet<true>(nodes, tris, otrav, rootRef, P, ubos, nFrames, packetFrames, validBefore, nValid, q, hits,
                        blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), p, hit, valid, pid);
 }
 
@@ -653,15 +653,16 @@ __global__ __launch_bounds__(kBlock) void k_primary_shade(const TNode* __restric
                                                           const ObjTrav* __restrict__ otrav, DScene sc, Partition P,
                                                           const lpt_ubo* __restrict__ ubos, uint32_t nFrames, Queue out,
                                                           uint32_t* fillOut, uint32_t capPart, float4* __restrict__ samples,
-                                                          uint32_t maxBounces, int bsdfMode) {
+                                                          uint32_t maxBounces, int bsdfMode, uint32_t packetFrames) {
   __shared__ uint32_t lds[kBlock / 64 + 1];
   __shared__ WalkShared walk;
   Path p;
   Hit hit;
   bool valid;
   uint32_t pid;
-  primary_packet<false>(nodes, tris, otrav, sc.rootRef, P, ubos, nFrames, nullptr, 0u, PrimaryQueue{nullptr, nullptr, nullptr},
-                        nullptr, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), p, hit, valid, pid);
+  primary_packet<false>(nodes, tris, otrav, sc.rootRef, P, ubos, nFrames, packetFrames, nullptr, 0u,
+                        PrimaryQueue{nullptr, nullptr, nullptr}, nullptr, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), p, hit,
+                        valid, pid);
   // with a bounce limit of one every path ends at its first hit whatever direction is sampled there
   const bool last = maxBounces <= 1u;
   bool alive = false, began = false;
@@ -1334,13 +1335,25 @@ int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* 
 uint32_t* fills_of(const lpt_ctx* c, uint32_t b) { return c->dCounts + (size_t)b * kCursorWords; }
 uint32_t* cursors_of(const lpt_ctx* c, uint32_t b) { return c->dCounts + ((size_t)c->poolBounces + b) * kCursorWords; }
 
+// Frames per packet of the camera-ray kernels: the largest power of two <= 4 that divides the batch's frames
+// (LPT_PRIMARY_PACKET_FRAMES sets another limit up to 64; 1 = one 8x8 pixel block of one frame per packet).
+// Measured, 1080p, 64 frames per batch, whole step: 1 / 4 / 16 / 64 frames per packet — Cornell box 35.82 / 35.72 / 35.86 /
+// 35.96 ms, 400 k-triangle terrain 140.6 / 138.9 / 138.6 / 138.5 ms.  A pixel block's rays already share most of their
+// walk (the kernel is bound by vector issue, not by the size of the union), so narrower packets gain little.
+uint32_t packet_frames(int frames) {
+  static const int limit = std::getenv("LPT_PRIMARY_PACKET_FRAMES") ? std::atoi(std::getenv("LPT_PRIMARY_PACKET_FRAMES")) : 4;
+  uint32_t f = 1;
+  while (2 * f <= (uint32_t)std::min(limit, 64) && frames % (int)(2 * f) == 0) f *= 2;
+  return f;
+}
+
 // Camera rays of `frames` frames into queue `q` (as k_generate leaves them) and their closest hits into c->dHits.
 void launch_primary(lpt_ctx* c, const Queue& q, int frames) {
   const size_t paths = (size_t)frames * c->part.nSlots;
   if (paths == 0 || c->nValid == 0) return;
   const DScene sc = device_scene(c);
   hipLaunchKernelGGL(k_primary, dim3((unsigned)((paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sc.nodes, sc.tris,
-                     sc.otrav, sc.rootRef, c->part, c->dUbos, (uint32_t)frames, c->dValidBefore, c->nValid,
+                     sc.otrav, sc.rootRef, c->part, c->dUbos, (uint32_t)frames, packet_frames(frames), c->dValidBefore, c->nValid,
                      PrimaryQueue{q.o, q.d, q.m}, c->dHits);
 }
 
@@ -1351,7 +1364,7 @@ void launch_primary_shade(lpt_ctx* c, const Queue& out, int frames) {
   const DScene sc = device_scene(c);
   hipLaunchKernelGGL(k_primary_shade, dim3((unsigned)((paths + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, sc.nodes,
                      sc.tris, sc.otrav, sc, c->part, c->dUbos, (uint32_t)frames, out, fills_of(c, 1), c->capPart, c->dSamples,
-                     (uint32_t)c->maxBounces, c->bsdfMode);
+                     (uint32_t)c->maxBounces, c->bsdfMode, packet_frames(frames));
 }
 
 // Shading of bounce b: queue `in` with c->dHits -> queue `out`; fill counts of bounces b and b + 1.  The grid is

@@ -50,35 +50,42 @@ struct PrimaryQueue {
   float4* m;
 };
 
-// Path ids are frame-major, slot-minor (64 consecutive slots are one 8x8 pixel block), and a wave holds one
-// pixel block of one frame.  The waves of the launch are dealt out block-major: consecutive waves hold the
-// same pixel block in consecutive frames, so the waves resident on the chip at one time look at a small part
-// of the scene (they share its records in the caches), and the paths that go on are queued region by region
-// (measured against frame-major: +1.3 % on the Cornell box, +1.8 % on a 400 k-triangle terrain scene).
+// Path ids are frame-major, slot-minor (64 consecutive slots are one 8x8 pixel block).  A wave's packet holds
+// 64 / packetFrames consecutive slots in packetFrames consecutive frames (packetFrames: a power of two <= 64 that
+// divides nFrames; lane = frame offset * slots per packet + slot offset): with 1 it is one pixel block of one frame,
+// with 64 one pixel in 64 frames, whose camera rays differ by the jitter inside the pixel only and so walk through
+// nearly the same nodes and triangles — the packet's walk is the union of its lanes' walks, and that union is what
+// it costs.  The packets of the launch are dealt out slot-major: consecutive waves hold the same slots in
+// consecutive frames, so the waves resident on the chip at one time look at a small part of the scene (they share
+// its records in the caches), and the paths that go on are queued region by region (measured against frame-major:
+// +1.3 % on the Cornell box, +1.8 % on a 400 k-triangle terrain scene).
 // The number of slots must be a multiple of 64.  The camera ray is generated here and traced; on return
 // `valid` says whether the path id is a pixel of the image, `p` is the path at its first segment and `hit`
 // what that segment found.  With STORE the ray is also queued at index f*nValid + validBefore[slot] (or the
 // path id itself when validBefore is null: every slot a pixel) and hits[same index] = (t, obj, prim, 0).
-// `w` is the number of the wave's packet in the launch (wave-uniform; a number beyond the last pixel block is a packet
+// `w` is the number of the wave's packet in the launch (wave-uniform; a number beyond the last packet is a packet
 // without pixels).  Every thread returns (no early exit), so the caller may synchronise the workgroup afterwards.
 template <bool STORE>
 __device__ __forceinline__ void primary_packet(const TNode* __restrict__ nodes, const Tri* __restrict__ tris,
                                                const ObjTrav* __restrict__ otrav, uint32_t rootRef,
                                                const Partition& P, const lpt_ubo* __restrict__ ubos,
-                                               uint32_t nFrames, const uint32_t* __restrict__ validBefore,
-                                               uint32_t nValid, const PrimaryQueue& q, float4* __restrict__ hits,
-                                               uint32_t w, Path& p, Hit& hit, bool& valid, uint32_t& pid) {
+                                               uint32_t nFrames, uint32_t packetFrames,
+                                               const uint32_t* __restrict__ validBefore, uint32_t nValid,
+                                               const PrimaryQueue& q, float4* __restrict__ hits, uint32_t w, Path& p,
+                                               Hit& hit, bool& valid, uint32_t& pid) {
   const uint32_t lane = threadIdx.x & 63u;
-  // packet w of the launch: pixel block w / nFrames in frame w % nFrames
-  const uint32_t sb = w / nFrames, fw = w - sb * nFrames;
-  valid = sb < (P.nSlots >> 6);
-  pid = valid ? fw * P.nSlots + sb * 64u + lane : 0xFFFFFFFFu;
+  // packet w of the launch: slots [sb * perPacket, (sb + 1) * perPacket) in frames [fw, fw + packetFrames)
+  const uint32_t perPacket = 64u / packetFrames, chunks = nFrames / packetFrames;
+  const uint32_t sb = w / chunks, fw = (w - sb * chunks) * packetFrames + lane / perPacket;
+  const uint32_t slotOfLane = sb * perPacket + (lane & (perPacket - 1u));
+  valid = slotOfLane < P.nSlots;
+  pid = valid ? fw * P.nSlots + slotOfLane : 0xFFFFFFFFu;
   uint32_t i = pid;
   p.o = p.d = f3{0.0f, 0.0f, 1.0f};
   p.mask = p.acc = f3{0.0f, 0.0f, 0.0f};
   p.rng = Rng{0u, 0u};
   if (valid) {
-    const uint32_t f = pid / P.nSlots, slot = pid - f * P.nSlots;
+    const uint32_t f = fw, slot = slotOfLane;
     int x, y;
     valid = slot_to_pixel(P, slot, x, y);
     if (valid) {
