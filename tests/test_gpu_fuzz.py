@@ -435,3 +435,21 @@ def test_gpu_builders_stay_logarithmic_on_many_equal_boxes(device, which):
         if which == 1:
             assert worst <= 40, (name, worst)  # log2(20000 / 4) is 12.3
         assert dt < 20.0, (name, dt)
+
+
+@pytest.mark.gpu
+def test_walks_carried_across_many_groups_of_hits_match_the_oracle():
+    """k_shade sets Heitz walks that go on aside in a pool and advances them whenever enough wait; with the usual grid a
+    small test image gives a workgroup one or two groups of hits, so the pool is mostly run to its end at once.  Here
+    the grid is capped at one workgroup per CU (the cap is read when the library first launches the kernel, hence a
+    process of its own), so that every workgroup carries walks across many groups: random scenes with rough, metallic
+    and transmissive materials, 320x240, six frames, every organisation, bit for bit against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LPT_SHADE_BLOCKS_PER_CU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz", "parity_sweep.py"), "9400", "9406", "320", "240", "6"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "done 9400 9406 mismatches 0" in r.stdout
