@@ -94,8 +94,11 @@ typedef enum lpt_status {
 /* #define USE_MICROFACET, shaders/path_tracing.comp:22 */
 enum { LPT_BSDF_HEITZ = 0, LPT_BSDF_BASIC = 1 };
 /* Kernel organisation; all produce identical pixels.
- * AUTO (default): HYBRID; WAVEFRONT for batches of 18 Mi paths and more; PERSISTENT when
- *            the ray queues do not fit in device memory.
+ * AUTO (default): HYBRID; WAVEFRONT for batches large enough to amortise a launch pair per
+ *            bounce — judged by the path count and what the last finished call of the same scene,
+ *            image size and options took per path (nine 1080p frames of a Cornell box, four of a
+ *            400 k-triangle scene with rough materials; before there is such a call: batches of
+ *            18 Mi paths and more); PERSISTENT when the ray queues do not fit in device memory.
  * WAVEFRONT: one kernel per stage and bounce over ray queues in device memory (128 bytes of
  *            queues per path in flight); the first segment runs in the packet kernel, and from the
  *            bounce at which the queues have become short (by the last batch's fills) one persistent

@@ -1001,6 +1001,11 @@ struct lpt_ctx {
   // Reports of queue fills are only taken from batches of the current scene, image size and options: every
   // change of those starts a new generation, and a report carries the generation of the batch that wrote it.
   uint32_t reportGeneration = 1;
+  // Device time per Mi paths of the last finished lpt_render_frames call of this generation (0: none yet): what
+  // LPT_PIPELINE_AUTO predicts a batch's time by.
+  double msPerMiPath = 0.0;
+  uint32_t timedGeneration = 0;  // the generation the call recorded in evStart / evStop belonged to (0: not to be used)
+  bool callAllocated = false;    // the current lpt_render_frames call had to allocate device or pinned memory
   unsigned char* dStatic = nullptr;  // this GPU's copy of `scratch` (device address)
 
   // timing of the last lpt_render_frames call
@@ -1017,6 +1022,7 @@ namespace {
 // Queue-fill reports of earlier batches no longer describe what the next batch will do.
 void next_report_generation(lpt_ctx* c) {
   if (++c->reportGeneration == 0u) c->reportGeneration = 1u;  // 0 means "being written"
+  c->msPerMiPath = 0.0;
 }
 
 int fail(lpt_ctx* ctx, int code, const std::string& msg) {
@@ -1214,6 +1220,7 @@ int ensure_pool(lpt_ctx* c, int frames) {
   const bool oneQueue = c->activePipeline == LPT_PIPELINE_HYBRID && primary_packets() && primary_fused();
   const int arrays = c->activePipeline == LPT_PIPELINE_PERSISTENT ? 1 : (oneQueue ? 4 : 8);
   if (paths > c->poolPaths || arrays != c->poolArrays) {
+    c->callAllocated = true;
     dfree(c->dPool);
     c->poolPaths = 0;
     // A queue array holds kCursorRegions part queues.  A part receives the paths of every kCursorRegions-th
@@ -1246,12 +1253,14 @@ int ensure_pool(lpt_ctx* c, int frames) {
     c->poolArrays = arrays;
   }
   if (c->maxBounces + 1 > c->poolBounces) {
+    c->callAllocated = true;
     dfree(c->dCounts);
     c->poolBounces = 0;  // stays 0 if the allocation fails: the next call tries again instead of using a null array
     LPT_HIP(c, hipMalloc(&c->dCounts, 2 * kCursorWords * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
     c->poolBounces = c->maxBounces + 1;
   }
   if (frames > c->ubosCap) {
+    c->callAllocated = true;
     LPT_HIP(c, hipStreamSynchronize(c->stream));  // copies out of the old staging buffers are done
     dfree(c->dUbos);
     c->ubosCap = 0;
@@ -2050,6 +2059,9 @@ int lpt_set_options(lpt_ctx* c, int max_bounces, int bsdf_mode, int pipeline, in
   return LPT_OK;
 }
 
+// LPT_PIPELINE_AUTO takes the wavefront organisation when Mi paths x (ms per Mi path)^kAutoCostExponent reaches this.
+constexpr double kAutoCostExponent = 0.64, kAutoWavefrontScore = 8.5;
+
 int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   int rc = ready(c);
   if (rc) return rc;
@@ -2061,8 +2073,17 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   // in-flight fence here, src/RendererCore.cpp:376; this layer allows the host to run one call ahead of the GPU.)
   rc = check_flags(c);  // an earlier render was cut short and nobody has asked since
   if (rc) return rc;
+  // what the last call cost per path, if it has finished (the events are recorded anew below)
+  if (c->haveTiming && c->timedGeneration == c->reportGeneration && c->lastFrames > 0 && c->part.nSlots > 0 &&
+      hipEventQuery(c->evStop) == hipSuccess) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->evStart, c->evStop) == hipSuccess && ms > 0.0f)
+      c->msPerMiPath = (double)ms / ((double)c->lastFrames * c->part.nSlots / (1024.0 * 1024.0));
+  }
+  (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error
   c->evUsed = 0;
   c->haveTiming = false;
+  c->callAllocated = false;
   LPT_HIP(c, hipMemsetAsync(c->dTotals, 0, kTotalsWords * sizeof(unsigned long long), c->stream));
   LPT_HIP(c, hipEventRecord(c->evStart, c->stream));
   if (c->pipeline == LPT_PIPELINE_MEGAKERNEL) {
@@ -2083,11 +2104,20 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     //    persistent launch) keeps seven waves per SIMD in the search and full waves in shading: ahead once a
     //    batch amortises its launches.  Cornell box 1080p, G segments/s by frames per batch (wavefront / hybrid):
     //    2: 4.36 / 4.84, 4: 6.03 / 6.64, 6: 6.95 / 7.22, 8: 7.45 / 7.50, 10: 7.84 / 7.69, 12: 8.18 / 7.86, 16: 8.58 / 8.06,
-    //    24: 9.09 / 8.25: they cross at nine frames, 18 Mi paths;
+    //    24: 9.09 / 8.25: they cross at nine frames, 18 Mi paths, batches of 6 to 7 ms.  On a scene whose paths cost four
+    //    times as much (400 k-triangle terrain, rough materials; 1 / 2 / 4 / 8 frames: 1.57 / 1.90, 2.25 / 2.58, 2.85 / 2.78,
+    //    3.29 / 2.87) they cross at three to four frames, 7 Mi paths, batches of 10 ms: what a batch must amortise — the
+    //    launches and their tails, which grow with the cost of the scene's longest rays — lies between a number of
+    //    paths and a time.  The switch interpolates between the two scenes: wavefront when
+    //    Mi paths x (ms per Mi path)^0.64 >= 8.5 (Cornell box 15.8 x 0.37^0.64 = 8.4 at the crossing, terrain 6.7 x 1.49^0.64 =
+    //    8.7), the cost per path being what the last finished call of the same scene, size and options took (calls that
+    //    allocated memory aside); by the path count while there is no such call yet;
     //  - PERSISTENT (no queues, 16 instead of 64 / 128 bytes per path in flight) when the queues do not fit.
     c->activePipeline = c->pipeline;
     if (c->pipeline == LPT_PIPELINE_AUTO) {
-      const bool largeBatch = (double)fif * c->part.nSlots >= 18.0 * 1024 * 1024;
+      const double miPaths = (double)fif * c->part.nSlots / (1024.0 * 1024.0);
+      const bool largeBatch =
+          c->msPerMiPath > 0.0 ? miPaths * std::pow(c->msPerMiPath, kAutoCostExponent) >= kAutoWavefrontScore : miPaths >= 18.0;
       c->activePipeline = largeBatch ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_HYBRID;
     }
     rc = ensure_pool(c, fif);
@@ -2111,6 +2141,7 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   LPT_HIP(c, hipEventRecord(c->evStop, c->stream));
   c->lastFrames = (uint64_t)n_frames;
   c->haveTiming = true;
+  c->timedGeneration = c->callAllocated ? 0u : c->reportGeneration;  // a call that allocated says little about the next
   return LPT_OK;
 }
 
@@ -2166,6 +2197,7 @@ int lpt_render_frame_static(lpt_ctx* c, const lpt_ubo* ubo) {
     use.recorded = true;
     c->lastFrames = 1;
     c->haveTiming = true;
+    c->timedGeneration = c->reportGeneration;
   }
   return LPT_OK;
 }

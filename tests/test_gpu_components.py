@@ -487,3 +487,35 @@ def test_caller_owned_stream(cornell, cornell_oracle):
         assert np.array_equal(dev.read_accum(), ref) and dev.stats().segments == st["segments"]
     finally:
         dev.close()
+
+
+def test_automatic_organisation_follows_batch_size_and_measured_cost(cornell):
+    """LPT_PIPELINE_AUTO: small batches run the hybrid organisation, large ones the wavefront kernels; once a call of the
+    same scene, size and options has finished, the choice uses what that call took per path, and it stays the same
+    for batches far from the crossing (one and sixteen 1080p frames of the Cornell box; they cross at nine).  The image
+    does not depend on the choice."""
+    w, h, bounces = 1920, 1080, 4
+    ubos = L.frame_ubos(cornell.camera_world, cornell.fov_y, 16, seed=5)
+    dev = L.Device(0)
+    try:
+        dev.upload_scene(cornell)
+        dev.resize(w, h)
+        dev.set_options(bounces, L.BSDF_HEITZ, L.PIPELINE_AUTO, 0)
+        chosen = []
+        for k in range(3):  # no finished call yet, then two calls that have one
+            dev.render_frames(ubos[k:k + 1])
+            chosen.append(dev.stats().pipeline)
+        assert chosen == [L.PIPELINE_HYBRID] * 3
+        dev.resize(w, h)
+        for k in range(3):
+            dev.render_frames(ubos)
+            chosen.append(dev.stats().pipeline)
+        assert chosen[3:] == [L.PIPELINE_WAVEFRONT] * 3
+        auto = dev.read_accum()
+        dev.resize(w, h)
+        dev.set_options(bounces, L.BSDF_HEITZ, L.PIPELINE_HYBRID, 0)
+        for k in range(3):
+            dev.render_frames(ubos)
+        assert np.array_equal(dev.read_accum(), auto)
+    finally:
+        dev.close()
