@@ -249,7 +249,7 @@ def roofline(wl, scene, ubos, counters, used_pipeline, kernel_seg, ext_ms, ext_l
         except Exception:
             pass
     return {
-        "kernel": kernel + (f"<{stack['entries_per_lane']}>" if stack else ""), "bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": kernel + (f"<{stack['entries_per_lane']}{', guarded' if stack.get('guarded') else ''}>" if stack else ""), "bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": algorithmic_gbs / HBM_PEAK_GBS, "traffic": traffic,
         "cache_resident": bool(algorithmic_gbs > HBM_PEAK_GBS or (hbm["measured_gbs"] or algorithmic_gbs) < 0.5 * algorithmic_gbs),
         "note": f"achieved = algorithmic bytes of the segments {kernel} traced (bounces {lo} to {hi - 1}) / its time (HIP events "
@@ -281,7 +281,11 @@ def measure(dev, ubos, spp_step, steps, warmup, barrier):
         out["extend_launches"] += st.extend_launches
         out["device_ms"] += st.device_ms
         out["pipeline"] = st.pipeline
-        out["stack"] = {"need": int(st.stack_need), "entries_per_lane": int(st.stack_entries)}
+        out["stack"] = {"need": int(st.stack_need), "entries_per_lane": int(st.stack_entries),
+                        "guarded": bool(st.stack_entries < st.stack_need),
+                        "note": "need = the most entries any ray the scene's trees admit could hold; a guarded kernel keeps "
+                                "entries_per_lane in LDS and leaves the rare rays that want more to a small launch with "
+                                "stacks in memory"}
         ranges.append((int(st.timed_bounce_lo), int(st.timed_bounce_hi)))
     barrier()
     out["elapsed"] = time.perf_counter() - t0

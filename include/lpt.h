@@ -136,8 +136,11 @@ typedef struct lpt_stats {
   uint64_t kernel_segments; /* the segments traced by the launches that extend_ms times */
   uint32_t timed_bounce_lo; /* those launches traced the segments of bounces [lo, hi) (of the call's last batch; */
   uint32_t timed_bounce_hi; /*  the wavefront organisation chooses per batch where its persistent launch takes over) */
-  uint32_t stack_need;      /* traversal-stack entries the uploaded scene can need at once (computed at upload) */
-  uint32_t stack_entries;   /* entries per lane of the kernel variant that serves it: 16, 20, 24, 32, 48 or 64 */
+  uint32_t stack_need;      /* traversal-stack entries a ray could need at once by the shape of the uploaded trees
+                               (a bound over all rays, computed at upload) */
+  uint32_t stack_entries;   /* entries per lane the search kernel that ran keeps on chip: 16, 20, 24, 32, 48 or 64.
+                               Below stack_need only for the wavefront organisation's search kernel, which then leaves
+                               the rare rays that want more to a small launch with stacks in device memory */
 } lpt_stats;
 
 /* ---- context ---------------------------------------------------------------- */

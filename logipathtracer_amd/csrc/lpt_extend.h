@@ -35,9 +35,13 @@ namespace lpt {
 // [12] longest time a wave went on after the queue ran dry, [14] sum of those times, [15] sum of all wave
 // times (100 MHz ticks); [16 + k] rays that took 32k .. 32k+31 steps (the counting slows the kernel down)
 __device__ unsigned long long g_extendStats[16 + 64];
+// rays by the most stack entries they held at one time
+__device__ unsigned long long g_extendDepth[64];
 #define LPT_XSTAT(k, lanes) (++xsR[k], xsL[k] += (uint32_t)(lanes))
+#define LPT_XDEPTH() (xsDepth = max(xsDepth, sp))
 #else
 #define LPT_XSTAT(k, lanes) ((void)0)
+#define LPT_XDEPTH() ((void)0)
 #endif
 
 // Rays are handed out in chunks of kFetchChunk.  The queue consists of kCursorRegions regions (its
@@ -92,13 +96,26 @@ constexpr int kStFetch = 0, kStInner = 1, kStTri = 2, kStObj = 3, kStDone = 4;
 // kCacheStride words: 80 bytes, so that 16-byte reads at unrelated nodes spread over all banks.
 constexpr int kCacheStride = 20;
 
+// Rays a GUARDed launch could not finish within its S stack entries: their queue indices, for extend_deep.
+struct DeepList {
+  uint32_t* count;  // entries so far (zeroed before the launch)
+  uint32_t* index;  // room for every ray of the queue
+};
+
 // `stack` is the workgroup's LDS array of S entries per thread, laid out [entry][thread]; `cache` one of
 // CACHE * kCacheStride words (unused if CACHE == 0).
-template <int S, int BLOCK, int CACHE>
+// GUARD: for scenes whose trees may want more than S entries for some ray.  The bound computed at upload is over
+// all rays a tree admits; what rays really hold is far less (of 395 M rays of a 400 k-triangle scene whose bound is
+// 20, 99.97 % never hold more than 12 entries and 83 more than 15).  A lane whose ray is about to need entry S
+// drops the ray — its index goes to `deep`, nothing is written for it — and takes the next one; a small launch
+// afterwards (extend_deep) searches the listed rays from the start with their stacks in global memory: the same
+// visits in the same order, so the same hits.  This lets every scene run the S = 16 instance with its eight waves
+// per SIMD and 48 cached nodes.
+template <int S, int BLOCK, int CACHE, bool GUARD = false>
 __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4* __restrict__ qo,
                                                   const float4* __restrict__ qd, const QueueFill& fill,
                                                   float4* __restrict__ hits, uint32_t* cursor, uint32_t* stack,
-                                                  float* cache) {
+                                                  float* cache, DeepList deep = DeepList{nullptr, nullptr}) {
   uint32_t* stk = &stack[threadIdx.x];
   if (CACHE > 0) {
     const uint32_t words = min((uint32_t)CACHE, sc.nNodes) * 16u;
@@ -127,6 +144,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
   int sp = 0;
 
 #ifdef LPT_EXTEND_STATS
+  int xsDepth = 0;
   uint32_t xsR[8] = {}, xsL[8] = {}, xsSteps = 0;
   const unsigned long long xsT0 = wall_clock64();
   unsigned long long xsTx = 0;
@@ -148,6 +166,7 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
 
     bool stepped = false;  // this lane advanced and holds a new `cur` (or needs a pop)
     bool needPop = false;
+    bool tooDeep = false;  // GUARD: this lane's ray is about to need more entries than the LDS stack has
 
     // Idle lanes are pure loss, so refill as soon as a fair number waits (or nothing else is left).
     if (nF > 0 && (nF >= LPT_FETCH_THRESHOLD || busy == 0)) {
@@ -218,7 +237,14 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
           box_test_pair(co, cinv, q0, q1, q2, hit.t, h0, h1);
           LPT_XSTEP();
           const uint32_t r0 = as_uint(q3.x), r1 = as_uint(q3.y);
-          if (h0 && h1) stk[(sp++) * BLOCK] = r0;
+          if (h0 && h1) {
+            if (GUARD && sp >= S) {  // no room for the other child
+              tooDeep = true;
+              break;
+            }
+            stk[(sp++) * BLOCK] = r0;
+            LPT_XDEPTH();
+          }
           cur = h1 ? r1 : r0;
           if (!(h0 || h1)) cur = stk[(--sp) * BLOCK];
           // a lane leaves the burst when its next reference is no inner node (the marker, leaves and
@@ -261,9 +287,12 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
         const uint32_t count = leaf_count(cur);
         if (count == 0u) {
           needPop = true;
+        } else if (GUARD && sp + (count > 1u ? 2 : 1) > S) {
+          tooDeep = true;
         } else {
           if (count > 1u) stk[(sp++) * BLOCK] = make_leaf_ref(first + 1u, count - 1u);
           stk[(sp++) * BLOCK] = kRefMarker;
+          LPT_XDEPTH();
           const float4* oq = record_words(sc.otrav, first);
           const float4 r0 = oq[0], r1 = oq[1], r2 = oq[2], r3 = oq[3];
           const float rows[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
@@ -279,6 +308,12 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       }
     }
 
+    if (GUARD && tooDeep) {  // rare: the ray is left to extend_deep, the lane is free for the next one
+      deep.index[atomicAdd(deep.count, 1u)] = rayIdx;
+      state = kStFetch;
+      stepped = false;
+    }
+
     // Common tail: take the next reference off the stack if needed and decide what the
     // lane waits for next.
     if (stepped) {
@@ -290,7 +325,9 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
       if (cur == kRefSentinel) {
 #ifdef LPT_EXTEND_STATS
         atomicAdd(&g_extendStats[16 + min(xsSteps >> 5, 63u)], 1ull);
+        atomicAdd(&g_extendDepth[min(xsDepth, 63)], 1ull);
         xsSteps = 0;
+        xsDepth = 0;
 #endif
         hits[rayIdx] = make_float4(hit.t, as_float(hit.obj), as_float(hit.prim), 0.0f);
         state = kStFetch;
@@ -317,6 +354,23 @@ __device__ __forceinline__ void extend_persistent(const DScene& sc, const float4
     atomicAdd(&g_extendStats[15], t1 - xsT0);
   }
 #endif
+}
+
+// The rays a GUARDed launch listed, one per wave (a ray is a chain of dependent loads; rays side by side in a wave
+// would wait for the longest of them), searched by lane 0 with its stack in global memory: `columns` holds
+// kDeepEntries words per wave of the grid.  intersect_scene is the walk extend_persistent's steps are cut from.
+constexpr int kDeepEntries = 64;  // the deepest stack an uploaded scene may need
+__device__ __forceinline__ void extend_deep(const DScene& sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+                                            const DeepList& deep, float4* __restrict__ hits, uint32_t* columns) {
+  const uint32_t n = *deep.count;
+  const uint32_t wavesPerBlock = blockDim.x >> 6, wave = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);
+  if ((threadIdx.x & 63u) != 0u) return;
+  for (uint32_t k = wave; k < n; k += gridDim.x * wavesPerBlock) {
+    const uint32_t i = deep.index[k];
+    const float4 o = qo[i], d = qd[i];
+    const Hit h = intersect_scene(sc, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, columns + (size_t)wave * kDeepEntries, 1);
+    hits[i] = make_float4(h.t, as_float(h.obj), as_float(h.prim), 0.0f);
+  }
 }
 
 }  // namespace lpt

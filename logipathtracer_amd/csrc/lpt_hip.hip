@@ -119,11 +119,12 @@ __global__ __launch_bounds__(kBlock) void k_generate(Partition P, const lpt_ubo*
 #else
 #define LPT_EXTEND_MIN_WAVES(S) ((S) <= 16 ? 8 : 1)
 #endif
-template <int S>
+// GUARD (see extend_persistent): for scenes whose trees may want more than S entries; rays that do go to `deep`.
+template <int S, bool GUARD = false>
 __attribute__((amdgpu_waves_per_eu(LPT_EXTEND_MIN_WAVES(S), 8)))
 __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __restrict__ qo,
                                                    const float4* __restrict__ qd, QueueFill fill,
-                                                   float4* __restrict__ hits, uint32_t* cursor) {
+                                                   float4* __restrict__ hits, uint32_t* cursor, DeepList deep) {
 // The hottest nodes (the top of the object tree and of the largest meshes) in LDS: as many as fit beside the stacks
 // without costing a resident workgroup — 48 beside eight workgroups' 16-entry stacks, 24 beside seven workgroups'
 // 20-entry stacks.  Measured: 24 nodes -2 % kernel time on the Cornell box, -6 % on a 70-object scene; sizes that cost
@@ -134,7 +135,15 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4* __re
   constexpr int kCacheNodes = LPT_EXTEND_CACHE_NODES;
   __shared__ uint32_t stack[S * kBlock];
   __shared__ __attribute__((aligned(16))) float cache[kCacheNodes > 0 ? kCacheNodes * kCacheStride : 4];
-  extend_persistent<S, kBlock, kCacheNodes>(sc, qo, qd, fill, hits, cursor, stack, cache);
+  extend_persistent<S, kBlock, kCacheNodes, GUARD>(sc, qo, qd, fill, hits, cursor, stack, cache, deep);
+}
+
+// The rays a guarded k_extend launch listed (see extend_deep).
+constexpr int kDeepBlock = 256, kDeepGrid = 256;
+__global__ __launch_bounds__(kDeepBlock) void k_extend_deep(DScene sc, const float4* __restrict__ qo,
+                                                            const float4* __restrict__ qd, DeepList deep,
+                                                            float4* __restrict__ hits, uint32_t* columns) {
+  extend_deep(sc, qo, qd, deep, hits, columns);
 }
 
 // Camera rays of a batch: generated, queued for the shading kernel and traced, 64 consecutive path ids
@@ -1007,6 +1016,9 @@ struct lpt_ctx {
   uint32_t timedGeneration = 0;  // the generation the call recorded in evStart / evStop belonged to (0: not to be used)
   bool callAllocated = false;    // the current lpt_render_frames call had to allocate device or pinned memory
   unsigned char* dStatic = nullptr;  // this GPU's copy of `scratch` (device address)
+  uint32_t* dDeepIndex = nullptr;    // guarded k_extend: queue indices of the rays left to k_extend_deep
+  size_t deepEntries = 0;
+  uint32_t* dDeepColumns = nullptr;  // k_extend_deep: a stack in memory per wave of its grid
 
   // timing of the last lpt_render_frames call
   hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -1075,8 +1087,11 @@ void free_textures(lpt_ctx* c) {
 void free_pool(lpt_ctx* c) {
   dfree(c->dPool);
   dfree(c->dCounts);
+  dfree(c->dDeepIndex);
+  dfree(c->dDeepColumns);
   c->poolPaths = 0;
   c->poolBounces = 0;
+  c->deepEntries = 0;
 }
 
 DScene device_scene(const lpt_ctx* c) {
@@ -1213,6 +1228,8 @@ bool primary_fused() {
   return on;
 }
 
+constexpr size_t kCountSets = 3;  // per bounce: queue fill counts, ray cursors, deep-ray count
+
 int ensure_pool(lpt_ctx* c, int frames) {
   size_t paths = (size_t)frames * c->part.nSlots;
   // float4 arrays of one entry per path: wavefront 2 queues x 3 + hits + samples = 8; hybrid with the fused
@@ -1256,7 +1273,7 @@ int ensure_pool(lpt_ctx* c, int frames) {
     c->callAllocated = true;
     dfree(c->dCounts);
     c->poolBounces = 0;  // stays 0 if the allocation fails: the next call tries again instead of using a null array
-    LPT_HIP(c, hipMalloc(&c->dCounts, 2 * kCursorWords * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
+    LPT_HIP(c, hipMalloc(&c->dCounts, kCountSets * kCursorWords * (size_t)(c->maxBounces + 1) * sizeof(uint32_t)));
     c->poolBounces = c->maxBounces + 1;
   }
   if (frames > c->ubosCap) {
@@ -1311,12 +1328,13 @@ int grid_for(const lpt_ctx* c, size_t items, int blocksPerCU) {
   return (int)std::max<size_t>(1, std::min(need, cap));
 }
 
-template <int S>
-int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* cursor, size_t maxItems) {
+// `deepCount`: GUARD only — a zeroed word for the number of rays the launch leaves to k_extend_deep.
+template <int S, bool GUARD>
+int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* cursor, size_t maxItems, uint32_t* deepCount) {
   // persistent grid: exactly as many workgroups as are resident at once (registers and LDS decide)
   static const int resident = [] {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<S>, kBlock, 0) != hipSuccess || n < 1) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<S, GUARD>, kBlock, 0) != hipSuccess || n < 1) n = 4;
     return n;
   }();
   int perCU = resident;
@@ -1324,25 +1342,61 @@ int launch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* cu
   if (capPerCU > 0) perCU = std::min(perCU, capPerCU);
   size_t need = (maxItems + kBlock - 1) / kBlock;
   int grid = (int)std::max<size_t>(1, std::min<size_t>(need, (size_t)c->numCUs * perCU));
-  hipLaunchKernelGGL(k_extend<S>, dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), q.o, q.d,
-                     QueueFill{fill, c->capPart}, c->dHits, cursor);
+  DeepList deep{nullptr, nullptr};
+  if (GUARD) {
+    // room for every ray of the queue in the list, and the stacks in memory of k_extend_deep's waves
+    const size_t entries = (size_t)c->capPart * kCursorRegions;
+    if (entries > c->deepEntries) {
+      dfree(c->dDeepIndex);
+      c->deepEntries = 0;
+      c->callAllocated = true;
+      LPT_HIP(c, hipMalloc(&c->dDeepIndex, entries * sizeof(uint32_t)));
+      c->deepEntries = entries;
+    }
+    if (!c->dDeepColumns) {
+      c->callAllocated = true;
+      LPT_HIP(c, hipMalloc(&c->dDeepColumns, (size_t)kDeepGrid * (kDeepBlock / 64) * kDeepEntries * sizeof(uint32_t)));
+    }
+    deep = DeepList{deepCount, c->dDeepIndex};
+  }
+  hipLaunchKernelGGL((k_extend<S, GUARD>), dim3(grid), dim3(kBlock), 0, c->stream, device_scene(c), q.o, q.d,
+                     QueueFill{fill, c->capPart}, c->dHits, cursor, deep);
+  if (GUARD)
+    hipLaunchKernelGGL(k_extend_deep, dim3(kDeepGrid), dim3(kDeepBlock), 0, c->stream, device_scene(c), q.o, q.d, deep,
+                       c->dHits, c->dDeepColumns);
   return 0;
 }
 
-// Stack depth of the kernel instance: the smallest that holds the uploaded trees.
-// `fill`: the queue's set of fill counts, `cursor`: a zeroed set of cursors
-int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* cursor, size_t maxItems) {
-  if (c->stackNeed <= 16) return launch_extend<16>(c, q, fill, cursor, maxItems);
-  if (c->stackNeed <= 20) return launch_extend<20>(c, q, fill, cursor, maxItems);
-  if (c->stackNeed <= 24) return launch_extend<24>(c, q, fill, cursor, maxItems);
-  if (c->stackNeed <= 32) return launch_extend<32>(c, q, fill, cursor, maxItems);
-  if (c->stackNeed <= 48) return launch_extend<48>(c, q, fill, cursor, maxItems);
-  return launch_extend<64>(c, q, fill, cursor, maxItems);
+// Which k_extend instance serves a scene whose trees may need `stackNeed` entries: up to 20 the instance whose LDS
+// stacks hold that bound (16 entries: eight waves per SIMD; 20: seven), beyond that the guarded 16-entry instance
+// instead of 24 / 32 / 48 / 64 entries at six / four / three / two waves.  Measured on a 400 k-triangle scene, k_extend
+// per launch: bound 20 (host SAH trees) 30.1 ms exact, 30.5 guarded (the follow-up launch for the few deep rays costs
+// more than the eighth wave brings); bound 22 (GPU LBVH trees) 36.6 ms with 24-entry stacks, 35.5 guarded.
+// LPT_EXTEND_EXACT_STACK=1 / 0 forces the exact instances / the guarded one wherever the bound exceeds 16.
+bool extend_guarded(const lpt_ctx* c) {
+  static const int forced = std::getenv("LPT_EXTEND_EXACT_STACK") ? std::atoi(std::getenv("LPT_EXTEND_EXACT_STACK")) : -1;
+  if (c->stackNeed <= 16) return false;
+  if (forced >= 0) return forced == 0;
+  return c->stackNeed > 20;
 }
 
+// `fill`: the queue's set of fill counts, `cursor`: a zeroed set of cursors, `deepCount`: a zeroed word
+int dispatch_extend(lpt_ctx* c, const Queue& q, const uint32_t* fill, uint32_t* cursor, size_t maxItems, uint32_t* deepCount) {
+  if (c->stackNeed <= 16) return launch_extend<16, false>(c, q, fill, cursor, maxItems, nullptr);
+  if (extend_guarded(c)) return launch_extend<16, true>(c, q, fill, cursor, maxItems, deepCount);
+  if (c->stackNeed <= 20) return launch_extend<20, false>(c, q, fill, cursor, maxItems, nullptr);
+  if (c->stackNeed <= 24) return launch_extend<24, false>(c, q, fill, cursor, maxItems, nullptr);
+  if (c->stackNeed <= 32) return launch_extend<32, false>(c, q, fill, cursor, maxItems, nullptr);
+  if (c->stackNeed <= 48) return launch_extend<48, false>(c, q, fill, cursor, maxItems, nullptr);
+  return launch_extend<64, false>(c, q, fill, cursor, maxItems, nullptr);
+}
+
+// c->dCounts holds kCountSets sets of kCursorWords words per bounce, zeroed before every batch.
 // The set of fill counts of bounce b's queue / the set of ray cursors for bounce b's launch.
 uint32_t* fills_of(const lpt_ctx* c, uint32_t b) { return c->dCounts + (size_t)b * kCursorWords; }
 uint32_t* cursors_of(const lpt_ctx* c, uint32_t b) { return c->dCounts + ((size_t)c->poolBounces + b) * kCursorWords; }
+// The word that counts the rays bounce b's guarded k_extend launch leaves to k_extend_deep.
+uint32_t* deep_count_of(const lpt_ctx* c, uint32_t b) { return c->dCounts + (2 * (size_t)c->poolBounces + b) * kCursorWords; }
 
 // Frames per packet of the camera-ray kernels: the largest power of two <= 4 that divides the batch's frames
 // (LPT_PRIMARY_PACKET_FRAMES sets another limit up to 64; 1 = one 8x8 pixel block of one frame per packet).
@@ -1401,7 +1455,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   if (rc) return rc;
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, 2 * kCursorWords * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, kCountSets * kCursorWords * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   rc = stage_frames(c, ubos, frames, true);
   if (rc) return rc;
   if (c->nValid && !primary_packets())  // the packet kernel generates the camera rays itself
@@ -1460,7 +1514,7 @@ int render_batch_wavefront(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
       launch_primary(c, in, frames);
     } else {  // the k_extend launches are timed one by one (lpt_stats.extend_ms)
       LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
-      dispatch_extend(c, in, fills_of(c, b), cursors_of(c, b), paths);
+      dispatch_extend(c, in, fills_of(c, b), cursors_of(c, b), paths, deep_count_of(c, b));
       LPT_HIP(c, hipEventRecord(c->evPool[c->evUsed++], c->stream));
     }
     launch_shade(c, in, out, b, nB, paths);
@@ -1538,7 +1592,7 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
   const size_t paths = (size_t)frames * c->part.nSlots;
   const uint32_t nB = (uint32_t)c->maxBounces;
   // (poolBounces >= 2: the sets of bounce 0 and bounce 1 exist)
-  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, 2 * kCursorWords * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
+  LPT_HIP(c, hipMemsetAsync(c->dCounts, 0, kCountSets * kCursorWords * (size_t)c->poolBounces * sizeof(uint32_t), c->stream));
   rc = stage_frames(c, ubos, frames, true);
   if (rc) return rc;
   rc = ensure_events(c, c->evUsed + 2);
@@ -1554,7 +1608,7 @@ int render_batch_hybrid(lpt_ctx* c, const lpt_ubo* ubos, int frames) {
     } else {
       hipLaunchKernelGGL(k_generate, dim3(grid_for(c, paths, 8)), dim3(kBlock), 0, c->stream, c->part, c->dUbos,
                          (uint32_t)frames, q0, c->dValidBefore, c->nValid);
-      dispatch_extend(c, q0, fills_of(c, 0), cursors_of(c, 0), paths);
+      dispatch_extend(c, q0, fills_of(c, 0), cursors_of(c, 0), paths, deep_count_of(c, 0));
       launch_shade(c, q0, q1, 0, nB, paths);
     }
   }
@@ -2234,6 +2288,11 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
     std::fprintf(stderr, "extend rays by steps (bins of 32):");
     for (int k = 0; k < 64 && t[16 + k]; ++k) std::fprintf(stderr, " %llu", t[16 + k]);
     std::fprintf(stderr, "\n");
+    unsigned long long d[64];
+    LPT_HIP(c, hipMemcpyFromSymbol(d, HIP_SYMBOL(lpt::g_extendDepth), sizeof d));
+    std::fprintf(stderr, "extend rays by most stack entries held:");
+    for (int k = 0; k < 64; ++k) std::fprintf(stderr, " %llu", d[k]);
+    std::fprintf(stderr, "\n");
   }
 #endif
 #ifdef LPT_TRACE_STATS
@@ -2267,7 +2326,10 @@ int lpt_get_stats(lpt_ctx* c, lpt_stats* out) {
   out->timed_bounce_lo = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? 0u : c->timedLo;
   out->timed_bounce_hi = c->activePipeline == LPT_PIPELINE_MEGAKERNEL ? (uint32_t)c->maxBounces : c->timedHi;
   out->stack_need = (uint32_t)c->stackNeed;
-  out->stack_entries = c->stackNeed <= 16 ? 16u : c->stackNeed <= 20 ? 20u : c->stackNeed <= 24 ? 24u : c->stackNeed <= 32 ? 32u
+  // what the search kernel that ran keeps in LDS: k_extend 16 entries per lane, guarded if the scene's bound is higher
+  // (rays that outgrow them are searched again with a stack in memory); the other kernels the scene's bound
+  out->stack_entries = c->stackNeed <= 16 || (c->activePipeline == LPT_PIPELINE_WAVEFRONT && extend_guarded(c)) ? 16u
+                       : c->stackNeed <= 20 ? 20u : c->stackNeed <= 24 ? 24u : c->stackNeed <= 32 ? 32u
                        : c->stackNeed <= 48 ? 48u : 64u;
   return LPT_OK;
 }

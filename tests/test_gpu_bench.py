@@ -27,7 +27,9 @@ def _bench(*args, timeout=400):
 def _check_roofline(roof, with_digest):
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert roof["kernel"].split("<")[0] in ("k_extend", "k_trace")
-    assert roof["traversal_stack"]["need"] <= roof["traversal_stack"]["entries_per_lane"] <= 64
+    stack = roof["traversal_stack"]
+    assert 16 <= stack["entries_per_lane"] <= 64 and stack["need"] <= 64
+    assert stack["guarded"] == (stack["entries_per_lane"] < stack["need"])  # fewer entries than the bound only if guarded
     assert roof["achieved"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     hbm, l1 = roof["hbm"], roof["l1_gather"]
     assert hbm["algorithmic_gbs"] == roof["achieved"] and hbm["algorithmic_frac"] == roof["frac"]

@@ -277,8 +277,10 @@ def _chain_scene(n_tris):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_tris", [14, 22, 30, 44, 60])
 def test_deep_trees_run_on_the_larger_stack_variants(device, n_tris):
-    """Chains of 14 to 60 levels need 16 to 62 stack entries: every stack size the kernels are built for
-    (16, 20, 24, 32, 48, 64) traces them like the oracle."""
+    """Chains of 14 to 60 levels need 16 to 62 stack entries: the persistent kernels run the instance that holds them
+    (16, 20, 24, 32, 48, 64), the wavefront organisation's search kernel its guarded 16-entry instance from 21 entries
+    on, whose rays outgrow the LDS stack here and are searched again by the follow-up launch; all trace like the oracle.
+    (test_search_kernel_instances_forced_either_way runs this with the choice forced both ways.)"""
     s = _chain_scene(n_tris)
     osc = O.OracleScene(s.objects, s.object_bvh, s.vertices, s.mesh_bvh)
     ubos = L.frame_ubos(s.camera_world, s.fov_y, 2, seed=n_tris)
@@ -453,3 +455,23 @@ def test_walks_carried_across_many_groups_of_hits_match_the_oracle():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "done 9400 9406 mismatches 0" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", ["0", "1"], ids=["guarded", "exact"])
+def test_search_kernel_instances_forced_either_way(exact):
+    """LPT_EXTEND_EXACT_STACK (read once per process, hence processes of their own): 1 runs the search kernel instance
+    whose LDS stacks hold the scene's bound (20 to 64 entries: not what deep scenes get by default), 0 the guarded
+    16-entry instance wherever the bound exceeds 16 (by default only beyond 20).  The chain scenes and a few random
+    scenes must match the oracle either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LPT_EXTEND_EXACT_STACK=exact)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_fuzz.py"), "-q", "-x", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k",
+                        "deep_trees or (random_scene_matches and (hard-1 or hard-2 or hard-3 or hard-4 or hard-5 or hard-6))"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
