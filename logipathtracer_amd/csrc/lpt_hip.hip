@@ -1013,6 +1013,7 @@ struct lpt_ctx {
   // Device time per Mi paths of the last finished lpt_render_frames call of this generation (0: none yet): what
   // LPT_PIPELINE_AUTO predicts a batch's time by.
   double msPerMiPath = 0.0;
+  int autoChoice = -1;  // what LPT_PIPELINE_AUTO chose last in this generation (-1: nothing yet)
   uint32_t timedGeneration = 0;  // the generation the call recorded in evStart / evStop belonged to (0: not to be used)
   bool callAllocated = false;    // the current lpt_render_frames call had to allocate device or pinned memory
   unsigned char* dStatic = nullptr;  // this GPU's copy of `scratch` (device address)
@@ -1035,6 +1036,7 @@ namespace {
 void next_report_generation(lpt_ctx* c) {
   if (++c->reportGeneration == 0u) c->reportGeneration = 1u;  // 0 means "being written"
   c->msPerMiPath = 0.0;
+  c->autoChoice = -1;
 }
 
 int fail(lpt_ctx* ctx, int code, const std::string& msg) {
@@ -1235,7 +1237,10 @@ int ensure_pool(lpt_ctx* c, int frames) {
   // float4 arrays of one entry per path: wavefront 2 queues x 3 + hits + samples = 8; hybrid with the fused
   // first segment the queue it writes + samples = 4; persistent samples only
   const bool oneQueue = c->activePipeline == LPT_PIPELINE_HYBRID && primary_packets() && primary_fused();
-  const int arrays = c->activePipeline == LPT_PIPELINE_PERSISTENT ? 1 : (oneQueue ? 4 : 8);
+  int arrays = c->activePipeline == LPT_PIPELINE_PERSISTENT ? 1 : (oneQueue ? 4 : 8);
+  // A pool laid out for more arrays serves an organisation that wants fewer (its arrays are among them): a context
+  // whose batches alternate between organisations keeps the larger pool instead of allocating anew every time.
+  if (paths <= c->poolPaths && arrays < c->poolArrays) arrays = c->poolArrays;
   if (paths > c->poolPaths || arrays != c->poolArrays) {
     c->callAllocated = true;
     dfree(c->dPool);
@@ -2114,7 +2119,7 @@ int lpt_set_options(lpt_ctx* c, int max_bounces, int bsdf_mode, int pipeline, in
 }
 
 // LPT_PIPELINE_AUTO takes the wavefront organisation when Mi paths x (ms per Mi path)^kAutoCostExponent reaches this.
-constexpr double kAutoCostExponent = 0.64, kAutoWavefrontScore = 8.5;
+constexpr double kAutoCostExponent = 0.64, kAutoWavefrontScore = 8.5, kAutoHysteresis = 0.12;
 
 int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
   int rc = ready(c);
@@ -2170,9 +2175,18 @@ int lpt_render_frames(lpt_ctx* c, const lpt_ubo* ubos, int n_frames) {
     c->activePipeline = c->pipeline;
     if (c->pipeline == LPT_PIPELINE_AUTO) {
       const double miPaths = (double)fif * c->part.nSlots / (1024.0 * 1024.0);
-      const bool largeBatch =
-          c->msPerMiPath > 0.0 ? miPaths * std::pow(c->msPerMiPath, kAutoCostExponent) >= kAutoWavefrontScore : miPaths >= 18.0;
+      bool largeBatch = miPaths >= 18.0;
+      if (c->msPerMiPath > 0.0) {
+        // near the crossing the two are equally fast and the measured cost wobbles: the last choice of this scene, size
+        // and options stands until the score has moved clearly past the threshold
+        const double score = miPaths * std::pow(c->msPerMiPath, kAutoCostExponent);
+        const double threshold = kAutoWavefrontScore * (c->autoChoice == LPT_PIPELINE_WAVEFRONT ? 1.0 - kAutoHysteresis
+                                                        : c->autoChoice == LPT_PIPELINE_HYBRID  ? 1.0 + kAutoHysteresis
+                                                                                                : 1.0);
+        largeBatch = score >= threshold;
+      }
       c->activePipeline = largeBatch ? LPT_PIPELINE_WAVEFRONT : LPT_PIPELINE_HYBRID;
+      c->autoChoice = c->activePipeline;
     }
     rc = ensure_pool(c, fif);
     if (rc == LPT_ERR_NOMEM && c->pipeline == LPT_PIPELINE_AUTO) {
